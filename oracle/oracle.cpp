@@ -1,0 +1,1556 @@
+// oracle.cpp — CPU restatement of the reference renderer's per-pixel trace loop.
+//
+// TEST INFRASTRUCTURE ONLY: the checker for the HIP path and the "port" CPU baseline.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+//
+// Parity status: the reference is Rust and cannot be built or run here, so this
+// restatement is pinned against the one reference output that matches the current
+// sources, gallery/glass_monkey.png (see tests/test_oracle_golden.py).  The random
+// sample positions of the AA pass and of the square light come from a counter-based
+// generator, because the reference's thread_rng stream cannot be reproduced
+// (parity unpinned for those two stages; pinned for everything deterministic).
+//
+// Every function cites the reference lines it follows.  The recursion, the per-level
+// transforms, the kd-tree and all quirks are kept; nothing is "improved".
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "oracle_math.hpp"
+#include "rt_amd.h"
+
+namespace orc {
+
+const double INF = std::numeric_limits<double>::infinity();
+const double PI = 3.14159265358979323846;
+
+struct Counters {
+    uint64_t rays_primary = 0, rays_secondary = 0, rays_shadow = 0, rays_aa = 0;
+    uint64_t instance_tests = 0, box_tests = 0, tri_tests = 0, shade_evals = 0, assert_failures = 0;
+    void add(const Counters& o) {
+        rays_primary += o.rays_primary; rays_secondary += o.rays_secondary; rays_shadow += o.rays_shadow; rays_aa += o.rays_aa;
+        instance_tests += o.instance_tests; box_tests += o.box_tests; tri_tests += o.tri_tests; shade_evals += o.shade_evals;
+        assert_failures += o.assert_failures;
+    }
+};
+thread_local Counters tl_counters;
+thread_local int tl_ray_class = 0;     // 0 primary, 1 aa primary (set by the driver)
+// When set, Intersect::transform recomputes the 4x4 inverse on every call like the
+// reference (src/geometry/matrix.rs:55-57); otherwise it uses the identical cached value.
+bool g_recompute_inverse = false;
+// Diagnostic switch: meshes answer closest-hit queries by testing every face.
+bool g_mesh_brute_force = false;
+// Golden-image mode: TranslucentShader as it was when the reference's gallery image was rendered.
+bool g_legacy_translucent = false;
+
+#define ORC_ASSERT(cond) do { if (!(cond)) tl_counters.assert_failures++; } while (0)
+
+// ---------------------------------------------------------------- Ray (src/geometry/ray.rs)
+struct Ray {
+    V3 origin, direction;
+    uint32_t depth;
+    Color contribution;
+    // identity for the counter-based RNG (not in the reference)
+    uint64_t stream;
+    uint32_t path;
+
+    static constexpr double MIN_DISTANCE = 0.001;       // :12
+    static constexpr double MIN_CONTRIBUTION = 0.003;   // :13
+
+    static Ray make(V3 origin, V3 direction, uint32_t depth) {             // :14-16
+        return {origin, direction, depth, {1.0, 1.0, 1.0}, 0, 1};
+    }
+    static Ray from_destination(V3 origin, V3 destination, uint32_t depth) {   // :18-20
+        return {origin, normalize(destination - origin), depth, {1.0, 1.0, 1.0}, 0, 1};
+    }
+    Ray contributes(Color percentage) const {                               // :22-26
+        Ray r = *this;
+        r.contribution = r.contribution * percentage;
+        return r;
+    }
+    double get_contribution() const { return contribution.r + contribution.g + contribution.b; }   // :28-32
+    Ray reflect_off(V3 hit_point, V3 surface_normal) const {               // :38-53
+        ORC_ASSERT(length(surface_normal) - 1.0 < 0.000001);
+        double d = dot(direction, surface_normal);
+        V3 reflection_direction = normalize(direction - 2.0 * d * surface_normal);
+        ORC_ASSERT(depth > 0);
+        Ray r = *this;
+        r.origin = hit_point; r.direction = reflection_direction; r.depth = depth - 1;
+        return r;
+    }
+    Ray transmit_through(V3 hit_point, V3 surface_normal, double refractive_index) const {   // :56-84
+        ORC_ASSERT(length(surface_normal) - 1.0 < 0.000001);
+        ORC_ASSERT(depth > 0);
+        double incident_cos = dot(direction, surface_normal);
+        if (incident_cos < 0.0) {
+            incident_cos = -incident_cos;
+            refractive_index = 1.0 / refractive_index;
+        } else {
+            surface_normal = surface_normal * -1.0;
+        }
+        double refraction_factor = 1.0 - refractive_index * refractive_index * (1.0 - incident_cos * incident_cos);
+        if (refraction_factor < 0.0) {
+            return reflect_off(hit_point, surface_normal);
+        }
+        V3 refraction_direction = refractive_index * direction + (refractive_index * incident_cos - std::sqrt(refraction_factor)) * surface_normal;
+        Ray r = *this;
+        r.origin = hit_point; r.direction = refraction_direction; r.depth = depth - 1;
+        return r;
+    }
+    V3 point_at_distance(double distance) const { return origin + (distance * direction); }   // :86-88
+    Ray transform(const M4& matrix) const {                                 // :90-97
+        Ray r = *this;
+        r.origin = transform_point(matrix, origin);
+        r.direction = normalize(transform_vector(matrix, direction));
+        return r;
+    }
+    Ray with_path(uint32_t ordinal) const { Ray r = *this; r.path = child_path(path, ordinal); return r; }
+};
+
+// TransformComponent (src/geometry.rs:83-110) + the cached inverse-transpose
+struct Xform {
+    M4 trans, inv_trans, inv_transpose;
+    Xform() : Xform(m4_identity()) {}
+    explicit Xform(const M4& t) : trans(t), inv_trans(m4_inverse(t)) { inv_transpose = m4_transpose(inv_trans); }
+};
+
+// ---------------------------------------------------------------- SurfaceCoord (src/geometry/surface_coord.rs)
+inline double fract(double x) { return x - std::trunc(x); }
+struct SurfaceCoord {
+    double u, v;
+    static SurfaceCoord make(double u, double v) {                          // :9-19
+        u = fract(u); v = fract(v);
+        u = u < 0.0 ? 1.0 + u : u;
+        v = v < 0.0 ? 1.0 + v : v;
+        return {u, v};
+    }
+    uint32_t get_u_index(uint32_t width) const { return (uint32_t)std::floor(fract(u) * (double)width); }    // :21-24
+    uint32_t get_v_index(uint32_t height) const { return (uint32_t)std::floor(fract(v) * (double)height); }  // :26-29
+    double get_u_decimal(uint32_t width) const { return fract(fract(u) * (double)width); }                   // :35-38
+    double get_v_decimal(uint32_t height) const { return fract(fract(v) * (double)height); }                 // :40-43
+};
+
+// ---------------------------------------------------------------- Intersect (src/geometry/intersect.rs)
+struct Intersect {
+    Ray ray;
+    double distance;
+    V3 hit_point, surface_normal, surface_tangent;
+    SurfaceCoord surface_coord;
+
+    Intersect transform(const Xform& x) const {                             // :31-45
+        const M4& matrix = x.trans;
+        Intersect r;
+        r.ray = ray.transform(matrix);
+        r.hit_point = transform_point(matrix, hit_point);
+        r.distance = length(r.hit_point - r.ray.origin);
+        // transform_normal: (matrix.inverse().transpose() * n).normalize()  (matrix.rs:55-57)
+        M4 it = g_recompute_inverse ? m4_transpose(m4_inverse(matrix)) : x.inv_transpose;
+        r.surface_normal = normalize(transform_vector(it, surface_normal));
+        r.surface_tangent = transform_vector(matrix, surface_tangent);
+        r.surface_coord = surface_coord;
+        return r;
+    }
+    Intersect contributes(Color percentage) const { Intersect r = *this; r.ray = ray.contributes(percentage); return r; }   // :47-56
+    Intersect invert_normal() const { Intersect r = *this; r.surface_normal = surface_normal * -1.0; return r; }            // :58-67
+};
+
+// ---------------------------------------------------------------- Intersectable (src/geometry.rs:15-30)
+struct Intersectable {
+    virtual ~Intersectable() = default;
+    virtual std::optional<Intersect> get_closest_intersect(const Ray& ray) const = 0;
+    virtual std::vector<Intersect> get_all_intersects(const Ray& ray) const {
+        std::vector<Intersect> v;
+        if (auto i = get_closest_intersect(ray)) v.push_back(*i);
+        return v;
+    }
+};
+using PrimPtr = std::shared_ptr<const Intersectable>;
+
+// ---- Sphere (src/primitive/sphere.rs)
+struct Sphere : Intersectable {
+    double radius;
+    explicit Sphere(double r) : radius(r) {}
+    static SurfaceCoord get_surface_coord(V3 hit_point) {                   // :18-29
+        hit_point = normalize(hit_point);
+        double azimuth = std::atan2(hit_point.z, hit_point.x);
+        double elevation = std::asin(hit_point.y);
+        double u = (azimuth / 2.0) / PI + 0.5;
+        double v = elevation / PI + 0.5;
+        ORC_ASSERT(u >= 0.0 && u <= 1.0);
+        ORC_ASSERT(v >= 0.0 && v <= 1.0);
+        return SurfaceCoord::make(u, v);
+    }
+    static std::optional<Intersect> intersect_from_distance(double dist, const Ray& ray) {   // :46-58
+        if (dist < Ray::MIN_DISTANCE) return std::nullopt;
+        V3 hit_point = ray.point_at_distance(dist);
+        SurfaceCoord sc = get_surface_coord(hit_point);
+        V3 n = normalize(hit_point);
+        V3 tangent = cross(n, cross(v3(0.0, 1.0, 0.0), n));
+        return Intersect{ray, dist, hit_point, n, tangent, sc};
+    }
+    std::pair<std::optional<Intersect>, std::optional<Intersect>> two_intersects(const Ray& ray) const {   // :31-44
+        V3 l = -1.0 * ray.origin;
+        double adj = dot(l, ray.direction);
+        double d2 = dot(l, l) - (adj * adj);
+        double radius2 = radius * radius;
+        if (d2 > radius2) return {std::nullopt, std::nullopt};
+        double thc = std::sqrt(radius2 - d2);
+        double t0 = adj - thc, t1 = adj + thc;
+        return {intersect_from_distance(t0, ray), intersect_from_distance(t1, ray)};
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :62-80
+        auto p = two_intersects(ray);
+        if (p.first) {
+            if (p.second) return p.first->distance < p.second->distance ? p.first : p.second;
+            return p.first;
+        }
+        return p.second;
+    }
+    std::vector<Intersect> get_all_intersects(const Ray& ray) const override {       // :82-92
+        auto p = two_intersects(ray);
+        std::vector<Intersect> v;
+        if (p.first) v.push_back(*p.first);
+        if (p.second) v.push_back(*p.second);
+        return v;
+    }
+};
+
+// ---- Plane / Rectangle / Triangle / Polygon (src/primitive/plane.rs)
+struct Plane : Intersectable {
+    V3 origin, normal, tangent;
+    V2 surface_scale;
+    SurfaceCoord get_surface_coord(V3 hit_point) const {                    // :37-42
+        V3 a = hit_point - origin;
+        V3 v = (dot(a, tangent) / dot(tangent, tangent)) * tangent;
+        V3 u = a - v;
+        return SurfaceCoord::make(fract(length(u) / surface_scale.x), fract(length(v) / surface_scale.y));
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :46-60
+        double origin_dot = dot(normal, ray.origin - origin);
+        double direction_dot = dot(normal, ray.direction);
+        double hit_distance = -origin_dot / direction_dot;
+        V3 hit_point = ray.point_at_distance(hit_distance);
+        if (hit_distance >= Ray::MIN_DISTANCE)
+            return Intersect{ray, hit_distance, hit_point, normal, tangent, get_surface_coord(hit_point)};
+        return std::nullopt;
+    }
+};
+
+struct Rectangle : Intersectable {
+    double width, height;
+    Rectangle(double w, double h) : width(w), height(h) {}
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :77-97
+        V3 surface_normal = v3(0.0, 0.0, 1.0);
+        double hit_distance = dot(ray.origin, surface_normal) / dot(ray.direction, surface_normal) * -1.0;
+        V3 hit_point = ray.point_at_distance(hit_distance);
+        double hb = width / 2.0, vb = height / 2.0;
+        if (hit_distance < Ray::MIN_DISTANCE || hit_point.x < -hb || hit_point.x > hb || hit_point.y < -vb || hit_point.y > vb)
+            return std::nullopt;
+        double u = (hit_point.x / hb + 1.0) / 2.0;
+        double v = (hit_point.y / vb + 1.0) / 2.0;
+        return Intersect{ray, hit_distance, hit_point, surface_normal, v3(0.0, 1.0, 0.0), SurfaceCoord::make(u, v)};
+    }
+};
+
+struct Triangle : Intersectable {
+    V3 vertices[3], edges[3];
+    double surface_coord_height, surface_coord_width;
+    V3 surface_tangent, surface_normal;
+    Triangle(V3 v1, V3 v2, V3 v3_) {                                        // :111-126
+        vertices[0] = v1; vertices[1] = v2; vertices[2] = v3_;
+        edges[0] = v2 - v1; edges[1] = v3_ - v2; edges[2] = v1 - v3_;
+        V3 a_side = -1.0 * edges[2];
+        V3 b_side = edges[0];
+        V3 h = a_side - (dot(a_side, b_side) / dot(b_side, b_side)) * b_side;
+        surface_tangent = normalize(h);
+        V3 w = a_side - h;
+        surface_coord_height = length(h);
+        surface_coord_width = std::fmax(length(w), length(b_side));
+        surface_normal = normalize(cross(edges[0], edges[1]));
+    }
+    SurfaceCoord get_surface_coord(double side_a, double side_b) const {    // :129-136
+        double side_c = length(edges[0]);
+        double cos_theta = (side_c * side_c + side_a * side_a - side_b * side_b) / (2.0 * side_c * side_a);
+        double x = side_a * cos_theta;
+        double y = std::sqrt(side_a * side_a - x * x);
+        return SurfaceCoord::make(x / surface_coord_width, y / surface_coord_height);
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :141-164
+        double origin_dot = dot(surface_normal, ray.origin - vertices[0]);
+        double direction_dot = dot(surface_normal, ray.direction);
+        double hit_distance = -origin_dot / direction_dot;
+        if (hit_distance > Ray::MIN_DISTANCE) {
+            V3 hit_point = ray.point_at_distance(hit_distance);
+            V3 v1 = hit_point - vertices[0], v2 = hit_point - vertices[1], v3_ = hit_point - vertices[2];
+            if (dot(cross(edges[0], v1), surface_normal) >= 0.0 && dot(cross(edges[1], v2), surface_normal) >= 0.0 &&
+                dot(cross(edges[2], v3_), surface_normal) >= 0.0) {
+                SurfaceCoord sc = get_surface_coord(length(v1), length(v2));
+                return Intersect{ray, hit_distance, hit_point, surface_normal, surface_tangent, sc};
+            }
+        }
+        return std::nullopt;
+    }
+};
+
+struct Polygon : Intersectable {
+    std::vector<V3> vertices, edges;
+    V3 normal;
+    explicit Polygon(std::vector<V3> verts) : vertices(std::move(verts)) {  // :181-202
+        size_t n = vertices.size();
+        edges.push_back(vertices[0] - vertices[n - 1]);
+        edges.push_back(vertices[1] - vertices[0]);
+        normal = normalize(cross(edges[0], edges[1]));
+        for (size_t i = 2; i + 1 < n; ++i) vertices[i] = vertices[i] - dot(vertices[i] - vertices[0], normal) * normal;
+        for (size_t i = 2; i < n; ++i) edges.push_back(vertices[i] - vertices[(i - 1) % n]);
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :207-234
+        double origin_dot = dot(normal, ray.origin - vertices[0]);
+        double direction_dot = dot(normal, ray.direction);
+        double hit_distance = -origin_dot / direction_dot;
+        if (hit_distance > Ray::MIN_DISTANCE) {
+            V3 hit_point = ray.point_at_distance(hit_distance);
+            bool inside = true;
+            for (size_t i = 0; i < vertices.size() && i < edges.size(); ++i)
+                if (!(dot(cross(edges[i], hit_point - vertices[i]), normal) >= 0.0)) { inside = false; break; }
+            if (inside) return Intersect{ray, hit_distance, hit_point, normal, v3(0.0, 1.0, 0.0), SurfaceCoord::make(0.0, 0.0)};
+        }
+        return std::nullopt;
+    }
+};
+
+// ---- Cube / Tetrahedron (src/primitive/cube.rs)
+template <class Base, int N>
+struct FacedSolid : Intersectable {
+    std::shared_ptr<Base> base_plane;
+    Xform face[N];
+    virtual SurfaceCoord transform_surface_coord(SurfaceCoord sc, int face_index) const = 0;
+    std::pair<std::optional<Intersect>, std::optional<Intersect>> two_intersects(const Ray& ray) const {   // :40-69, :131-163
+        std::pair<std::optional<Intersect>, std::optional<Intersect>> out;
+        for (int i = 0; i < N; ++i) {
+            Ray transformed_ray = ray.transform(face[i].inv_trans);
+            if (auto intersect = base_plane->get_closest_intersect(transformed_ray)) {
+                Intersect cur = intersect->transform(face[i]);
+                if (cur.distance >= Ray::MIN_DISTANCE) {
+                    cur.surface_coord = transform_surface_coord(intersect->surface_coord, i);
+                    if (out.first) {
+                        if (cur.distance < out.first->distance) { out.second = out.first; out.first = cur; }
+                        else out.second = cur;
+                        break;
+                    } else {
+                        out.first = cur;
+                    }
+                }
+            }
+        }
+        return out;
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override { return two_intersects(ray).first; }
+    std::vector<Intersect> get_all_intersects(const Ray& ray) const override {
+        auto p = two_intersects(ray);
+        std::vector<Intersect> v;
+        if (p.first) v.push_back(*p.first);
+        if (p.second) v.push_back(*p.second);
+        return v;
+    }
+};
+
+struct Cube : FacedSolid<Rectangle, 6> {
+    explicit Cube(double length) {                                          // :14-31
+        base_plane = std::make_shared<Rectangle>(length, length);
+        M4 t = translation(0.0, 0.0, length / 2.0);
+        face[0] = Xform(m4_mul(rotation_y(90.0), t));     // right
+        face[1] = Xform(m4_mul(rotation_y(-90.0), t));    // left
+        face[2] = Xform(t);                               // front
+        face[3] = Xform(m4_mul(rotation_y(180.0), t));    // back
+        face[4] = Xform(m4_mul(rotation_x(-90.0), t));    // top
+        face[5] = Xform(m4_mul(rotation_x(90.0), t));     // bottom
+    }
+    SurfaceCoord transform_surface_coord(SurfaceCoord sc, int f) const override {   // :12, :33-38
+        static const double off[6][2] = {{2.0, 1.0}, {0.0, 1.0}, {1.0, 1.0}, {3.0, 1.0}, {1.0, 2.0}, {1.0, 0.0}};
+        return SurfaceCoord::make((sc.u + off[f][0]) / 4.0, (sc.v + off[f][1]) / 3.0);
+    }
+};
+
+struct Tetrahedron : FacedSolid<Triangle, 4> {
+    explicit Tetrahedron(double size) {                                     // :103-122
+        double tri_height = size * std::sin(PI / 3.0);
+        base_plane = std::make_shared<Triangle>(v3(-size / 2.0, 0.0, 0.0), v3(size / 2.0, 0.0, 0.0), v3(0.0, 0.0, -tri_height));
+        M4 t = translation(0.0, 0.0, tri_height / 3.0);
+        M4 m0 = m4_mul(scaling(1.0, -1.0, 1.0), t);                                   // reflection(Axis::Y) * translation
+        M4 m1 = m4_mul(t, rotation_x(std::acos(1.0 / 3.0) * (180.0 / PI)));
+        face[0] = Xform(m0);
+        face[1] = Xform(m1);
+        face[2] = Xform(m4_mul(rotation_y(-120.0), m1));
+        face[3] = Xform(m4_mul(rotation_y(120.0), m1));
+    }
+    SurfaceCoord transform_surface_coord(SurfaceCoord sc, int f) const override {   // :124-129
+        return SurfaceCoord::make((sc.u + (double)f / 2.0) / 2.5, 1.0 - sc.v);
+    }
+};
+
+// ---- Polyhedron (src/primitive/polyhedron.rs)
+struct Polyhedron : Intersectable {
+    std::vector<Plane> planes;
+    bool check_bounds(const Intersect& it, size_t offset) const {           // :99-107
+        for (size_t i = 1; i < planes.size(); ++i) {
+            const Plane& p = planes[(i + offset) % planes.size()];
+            if (dot(p.origin - it.hit_point, p.normal) < 0.0) return false;
+        }
+        return true;
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :118-136
+        std::optional<Intersect> ret;
+        for (size_t i = 0; i < planes.size(); ++i) {
+            if (auto it = planes[i].get_closest_intersect(ray)) {
+                if (check_bounds(*it, i)) {
+                    if (!ret || it->distance < ret->distance) {
+                        Intersect m = *it;                                  // modify_surface_coord :109-113
+                        m.surface_coord = SurfaceCoord::make(((double)i + m.surface_coord.u) / (double)planes.size(), m.surface_coord.v);
+                        ret = m;
+                    }
+                }
+            }
+        }
+        return ret;
+    }
+};
+
+// ---- OneWay / Inverted (src/primitive.rs)
+struct OneWay : Intersectable {
+    PrimPtr primitive;
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :33-40
+        if (auto it = primitive->get_closest_intersect(ray))
+            if (dot(ray.direction, it->surface_normal) < 0.0) return it;
+        return std::nullopt;
+    }
+    std::vector<Intersect> get_all_intersects(const Ray& ray) const override {         // :42-45
+        std::vector<Intersect> out;
+        for (auto& it : primitive->get_all_intersects(ray))
+            if (dot(ray.direction, it.surface_normal) < 0.0) out.push_back(it);
+        return out;
+    }
+};
+struct Inverted : Intersectable {
+    PrimPtr primitive;
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :64-72
+        if (auto it = primitive->get_closest_intersect(ray))
+            if (dot(ray.direction, it->surface_normal) >= 0.0) { it->surface_normal = it->surface_normal * -1.0; return it; }
+        return std::nullopt;
+    }
+    std::vector<Intersect> get_all_intersects(const Ray& ray) const override {         // :74-80
+        auto v = primitive->get_all_intersects(ray);
+        for (auto& it : v) it.surface_normal = it.surface_normal * -1.0;
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------- Mesh + kd-tree (src/mesh.rs)
+struct Mesh;
+struct BoundingBox {
+    V3 max, min;
+    bool contains(V3 p) const {                                             // :46-50
+        return p.x < max.x && p.x > min.x && p.y < max.y && p.y > min.y && p.z < max.z && p.z > min.z;
+    }
+    bool contains_xy(V3 p) const { return p.x <= max.x && p.x >= min.x && p.y <= max.y && p.y >= min.y; }   // :52-55
+    bool contains_xz(V3 p) const { return p.x <= max.x && p.x >= min.x && p.z <= max.z && p.z >= min.z; }   // :57-60
+    bool contains_yz(V3 p) const { return p.y <= max.y && p.y >= min.y && p.z <= max.z && p.z >= min.z; }   // :62-65
+    // 0 = no result on this axis, 1 = hit (hit_point set)                  // :67-96
+    int check_axis(const Ray& ray, V3 axis, bool (BoundingBox::*check)(V3) const, V3& hit_point) const {
+        double axis_dot = dot(ray.direction, axis);
+        if (axis_dot < 0.0) {
+            double origin_dot = dot(axis, ray.origin - max);
+            if (origin_dot >= 0.0) {
+                double distance = -origin_dot / axis_dot;
+                V3 hp = ray.point_at_distance(distance);
+                if ((this->*check)(hp)) { hit_point = hp; return 1; }
+            }
+        } else if (axis_dot > 0.0) {
+            double origin_dot = -dot(axis, ray.origin - min);
+            if (origin_dot >= 0.0) {
+                double distance = origin_dot / axis_dot;
+                V3 hp = ray.point_at_distance(distance);
+                if ((this->*check)(hp)) { hit_point = hp; return 1; }
+            }
+        }
+        return 0;
+    }
+    enum Bound { Inside, Hit, Miss };
+    Bound check_intersect(const Ray& ray, V3& hit_point) const {            // :98-114
+        tl_counters.box_tests++;
+        if (contains(ray.origin)) return Inside;
+        if (check_axis(ray, v3(0, 0, 1), &BoundingBox::contains_xy, hit_point)) return Hit;   // FRONT
+        if (check_axis(ray, v3(1, 0, 0), &BoundingBox::contains_yz, hit_point)) return Hit;   // RIGHT
+        if (check_axis(ray, v3(0, 1, 0), &BoundingBox::contains_xz, hit_point)) return Hit;   // UP
+        return Miss;
+    }
+};
+
+inline double axis_value(int axis, V3 v) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+struct BoundingNode {
+    bool leaf = true;
+    int axis = 0;
+    double split = 0;
+    std::unique_ptr<BoundingNode> child[2];
+    std::vector<size_t> prims;
+    static constexpr size_t MAX_PRIMS = 40;                                 // :164
+    static constexpr uint8_t MAX_DEPTH = 33;                                // :165
+    struct Prim { size_t idx; V3 min, max; };
+
+    static std::unique_ptr<BoundingNode> split_node(int axis, uint8_t depth, std::vector<Prim> prims) {   // :281-332
+        auto node = std::make_unique<BoundingNode>();
+        if (depth == 0 || prims.size() <= MAX_PRIMS) {
+            for (auto& p : prims) node->prims.push_back(p.idx);
+            return node;
+        }
+        std::stable_sort(prims.begin(), prims.end(), [axis](const Prim& a, const Prim& b) { return axis_value(axis, a.min) < axis_value(axis, b.min); });
+        size_t half = prims.size() / 2;
+        std::vector<Prim> child2(prims.begin() + half, prims.end());
+        prims.resize(half);
+        double split = axis_value(axis, child2[0].min);
+        for (auto& p : prims)
+            if (axis_value(axis, p.max) >= split) child2.push_back(p);
+        int next_axis = (axis + 1) % 3;
+        node->leaf = false; node->axis = axis; node->split = split;
+        node->child[0] = split_node(next_axis, depth - 1, std::move(prims));
+        node->child[1] = split_node(next_axis, depth - 1, std::move(child2));
+        return node;
+    }
+    std::optional<Intersect> check_intersect(const Mesh& mesh, const Ray& ray, V3 min, V3 max) const;   // :167-279
+};
+
+struct Mesh : Intersectable {
+    std::vector<V3> positions, vertex_normals;
+    std::vector<V2> tex_coords;
+    struct Face { size_t a, b, c; };
+    std::vector<Face> faces;
+    std::vector<V3> face_normals;
+    std::vector<double> face_area;
+    V3 bmin, bmax;
+    std::unique_ptr<BoundingNode> root;
+
+    void finish() {                                                         // :396-413, :124-144
+        for (auto& f : faces) {
+            V3 a = cross(positions[f.b] - positions[f.a], positions[f.c] - positions[f.b]);
+            face_normals.push_back(normalize(a));
+            face_area.push_back(1.0 / length(a));
+        }
+        std::vector<BoundingNode::Prim> prims;
+        bmax = v3(-INF, -INF, -INF); bmin = v3(INF, INF, INF);
+        auto vmax = [](V3 a, V3 b) { return v3(std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)); };
+        auto vmin = [](V3 a, V3 b) { return v3(std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)); };
+        for (size_t i = 0; i < faces.size(); ++i) {
+            V3 a = positions[faces[i].a], b = positions[faces[i].b], c = positions[faces[i].c];
+            V3 mx = vmax(a, vmax(b, c)), mn = vmin(a, vmin(b, c));
+            bmax = vmax(mx, bmax); bmin = vmin(mn, bmin);
+            prims.push_back({i, mn, mx});
+        }
+        root = BoundingNode::split_node(0, BoundingNode::MAX_DEPTH, std::move(prims));
+    }
+    std::optional<Intersect> check_triangle(size_t face, const Ray& ray) const {   // :416-466
+        tl_counters.tri_tests++;
+        size_t i1 = faces[face].a, i2 = faces[face].b, i3 = faces[face].c;
+        V3 v1 = positions[i1], v2 = positions[i2], v3_ = positions[i3];
+        V3 e1 = v2 - v1, e2 = v3_ - v2;
+        V3 normal = face_normals[face];
+        double origin_dot = dot(normal, ray.origin - v1);
+        double direction_dot = dot(normal, ray.direction);
+        double hit_distance = -origin_dot / direction_dot;
+        if (hit_distance > Ray::MIN_DISTANCE) {
+            V3 hit_point = ray.point_at_distance(hit_distance);
+            V3 hit_v1 = hit_point - v1, hit_v2 = hit_point - v2, hit_v3 = hit_point - v3_;
+            V3 e3 = v1 - v3_;
+            V3 v = cross(e1, hit_v1);
+            if (dot(v, normal) < 0.0) return std::nullopt;
+            V3 w = cross(e2, hit_v2);
+            if (dot(w, normal) < 0.0) return std::nullopt;
+            V3 u = cross(e3, hit_v3);
+            if (dot(u, normal) < 0.0) return std::nullopt;
+            double uu = length(u) * face_area[face];
+            double vv = length(v) * face_area[face];
+            double ww = 1.0 - uu - vv;
+            V3 n = vertex_normals.size() > i1 ? ww * vertex_normals[i1] + uu * vertex_normals[i2] + vv * vertex_normals[i3] : normal;
+            SurfaceCoord sc = SurfaceCoord::make(0.0, 0.0);
+            if (tex_coords.size() > i1) {
+                V2 t = tex_coords[i1] * ww + tex_coords[i2] * uu + tex_coords[i3] * vv;
+                sc = SurfaceCoord::make(t.x, t.y);
+            }
+            return Intersect{ray, hit_distance, hit_point, n, v3(0.0, 1.0, 0.0), sc};
+        }
+        return std::nullopt;
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {   // :469-473, :146-148
+        if (g_mesh_brute_force) {   // diagnostic: exact closest hit over all faces, no kd-tree
+            std::optional<Intersect> best;
+            for (size_t f = 0; f < faces.size(); ++f)
+                if (auto it = check_triangle(f, ray))
+                    if (!best || it->distance < best->distance) best = it;
+            return best;
+        }
+        return root->check_intersect(*this, ray, bmin, bmax);
+    }
+};
+
+std::optional<Intersect> BoundingNode::check_intersect(const Mesh& mesh, const Ray& ray, V3 min, V3 max) const {
+    BoundingBox bb{max, min};
+    V3 hit_point;
+    switch (bb.check_intersect(ray, hit_point)) {
+        case BoundingBox::Hit: break;
+        case BoundingBox::Inside: hit_point = ray.origin; break;
+        case BoundingBox::Miss: return std::nullopt;
+    }
+    if (!leaf) {
+        V3 split_min = min, split_max = max;
+        if (axis == 0) { split_min.x = split; split_max.x = split; }
+        else if (axis == 1) { split_min.y = split; split_max.y = split; }
+        else { split_min.z = split; split_max.z = split; }
+        bool is_first = axis_value(axis, hit_point) <= split;
+        auto same_side = [&](double x) { return is_first ? x <= split : x > split; };
+        int first = is_first ? 0 : 1, second = is_first ? 1 : 0;
+        V3 first_min = is_first ? min : split_min, first_max = is_first ? split_max : max;
+        V3 second_min = is_first ? split_min : min, second_max = is_first ? max : split_max;
+        double min_distance = INF;
+        std::optional<Intersect> ret_int;
+        if (auto it = child[first]->check_intersect(mesh, ray, first_min, first_max)) {
+            ret_int = it;
+            if (same_side(axis_value(axis, it->hit_point))) return ret_int;
+            min_distance = it->distance;
+        }
+        if (auto it = child[second]->check_intersect(mesh, ray, second_min, second_max)) {
+            if (it->distance < min_distance) return it;
+        }
+        return ret_int;
+    }
+    double min_distance = INF;
+    std::optional<Intersect> ret_int;
+    for (size_t prim : prims) {
+        if (auto it = mesh.check_triangle(prim, ray)) {
+            if (it->distance < min_distance) { min_distance = it->distance; ret_int = it; }
+        }
+    }
+    return ret_int;
+}
+
+// ---------------------------------------------------------------- CSG (src/composite_shape.rs + composite_shape/*.rs)
+struct Compositable : Intersectable {
+    Xform transform;
+    virtual std::vector<const Compositable*> get_shapes() const = 0;
+};
+using CsgPtr = std::shared_ptr<const Compositable>;
+enum class HitDir { Enter, Exit };
+struct Tagged { size_t shape; HitDir dir; Intersect it; };
+
+inline HitDir hit_direction(const Intersect& it) {                          // :27-30
+    return dot(it.surface_normal, it.ray.direction) < 0.0 ? HitDir::Enter : HitDir::Exit;
+}
+inline std::vector<Tagged> merge(const std::vector<Tagged>& A, const std::vector<Tagged>& B) {   // :33-72
+    std::vector<Tagged> all;
+    all.reserve(A.size() + B.size());
+    size_t ia = 0, ib = 0;
+    while (ia < A.size() || ib < B.size()) {
+        if (ia < A.size()) {
+            if (ib < B.size()) {
+                if (A[ia].it.distance < B[ib].it.distance) all.push_back(A[ia++]);
+                else all.push_back(B[ib++]);
+            } else all.push_back(A[ia++]);
+        } else all.push_back(B[ib++]);
+    }
+    return all;
+}
+// check_get returns true for Control::Return                               // :75-123
+inline void calculate_intersects(const Compositable& comp, const Ray& ray_in,
+                                 const std::function<bool(size_t, const std::vector<bool>&, const Intersect&)>& check_get) {
+    Ray ray = ray_in.transform(comp.transform.inv_trans);
+    auto shapes = comp.get_shapes();
+    std::vector<std::vector<Tagged>> shape_intersects;
+    for (size_t i = 0; i < shapes.size(); ++i) {
+        auto its = shapes[i]->get_all_intersects(ray);
+        std::stable_sort(its.begin(), its.end(), [](const Intersect& a, const Intersect& b) { return a.distance < b.distance; });
+        std::vector<Tagged> t;
+        for (auto& x : its) t.push_back({i, hit_direction(x), x});
+        shape_intersects.push_back(std::move(t));
+    }
+    std::vector<bool> states;
+    for (auto& v : shape_intersects) states.push_back(!v.empty() && v.front().dir == HitDir::Exit);
+    std::vector<Tagged> all;
+    for (auto& v : shape_intersects) all = merge(all, v);
+    for (auto& t : all) {
+        if (check_get(t.shape, states, t.it.transform(comp.transform))) return;
+        states[t.shape] = !states[t.shape];
+    }
+}
+
+struct BaseShape : Compositable {                                           // base_shape.rs
+    PrimPtr primitive;
+    std::vector<const Compositable*> get_shapes() const override { return {this}; }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray_in) const override {   // :41-47
+        Ray ray = ray_in.transform(transform.inv_trans);
+        if (auto it = primitive->get_closest_intersect(ray)) return it->transform(transform);
+        return std::nullopt;
+    }
+    std::vector<Intersect> get_all_intersects(const Ray& ray_in) const override {         // :49-53
+        Ray ray = ray_in.transform(transform.inv_trans);
+        auto v = primitive->get_all_intersects(ray);
+        for (auto& it : v) it = it.transform(transform);
+        return v;
+    }
+};
+
+// A predicate decides per merged event whether to emit it (and with which normal).
+struct OpShape : Compositable {
+    uint32_t kind;
+    std::vector<CsgPtr> shapes;
+    std::vector<const Compositable*> get_shapes() const override {
+        std::vector<const Compositable*> v;
+        for (auto& s : shapes) v.push_back(s.get());
+        return v;
+    }
+    // returns 0 = skip, 1 = emit, 2 = emit with inverted normal
+    int predicate(size_t cur, const std::vector<bool>& st) const {
+        switch (kind) {
+            case RT_CSG_SUBTRACT:                                           // subtract_shape.rs:46-53
+                if (!st[1] && cur == 0) return 1;
+                if (st[0] && cur == 1) return 2;
+                return 0;
+            case RT_CSG_AND:                                                // and_shape.rs:25
+                return (st[1 - cur] || (st[0] && st[1])) ? 1 : 0;
+            case RT_CSG_MULTI_AND: {                                        // and_shape.rs:93
+                bool acc = true;
+                for (size_t i = 0; i < st.size(); ++i) acc = acc && (cur == i || st[i]);
+                return acc ? 1 : 0;
+            }
+            case RT_CSG_OR:                                                 // or_shape.rs:25-27
+                return (!(st[0] && st[1]) && ((!st[0] && !st[1]) || st[cur])) ? 1 : 0;
+            case RT_CSG_XOR:                                                // xor_shape.rs:25-33
+                if (!st[0] && !st[1]) return 1;
+                if ((st[0] && st[1]) || st[1 - cur]) return 2;
+                return 1;
+        }
+        return 0;
+    }
+    std::optional<Intersect> get_closest_intersect(const Ray& ray) const override {
+        std::optional<Intersect> ret;
+        calculate_intersects(*this, ray, [&](size_t cur, const std::vector<bool>& st, const Intersect& it) {
+            int p = predicate(cur, st);
+            if (p == 1) { ret = it; return true; }
+            if (p == 2) { ret = it.invert_normal(); return true; }
+            return false;
+        });
+        return ret;
+    }
+    std::vector<Intersect> get_all_intersects(const Ray& ray) const override {
+        std::vector<Intersect> ret;
+        calculate_intersects(*this, ray, [&](size_t cur, const std::vector<bool>& st, const Intersect& it) {
+            int p = predicate(cur, st);
+            if (p == 1) ret.push_back(it);
+            if (p == 2) ret.push_back(it.invert_normal());
+            return false;
+        });
+        return ret;
+    }
+};
+
+// ---------------------------------------------------------------- textures / normal maps
+// ImageTexture (src/texture.rs:30-69).  Rows are stored flipped vertically, as the
+// reference does at load (:38-47).  gamma_decode((c/255)) = powf(2.2) per tap
+// (src/color.rs:78-84) is tabulated: same function, same 256 inputs, same results.
+struct Image {
+    uint32_t width = 0, height = 0, channels = 3;
+    std::vector<uint8_t> px;   // flipped
+    const uint8_t* at(uint32_t x, uint32_t y) const { return &px[((size_t)y * width + x) * channels]; }
+};
+static double g_gamma_lut[256];
+static std::once_flag g_gamma_once;
+static void init_gamma() {
+    for (int i = 0; i < 256; ++i) g_gamma_lut[i] = std::pow((double)i / 255.0, 2.2);
+}
+inline Color from_rgb(const uint8_t* p) { return {g_gamma_lut[p[0]], g_gamma_lut[p[1]], g_gamma_lut[p[2]]}; }
+
+inline Color texture_get_color(const Image& im, SurfaceCoord sc) {          // texture.rs:52-69
+    uint32_t u = sc.get_u_index(im.width - 1), v = sc.get_v_index(im.height - 1);
+    Color up_left = from_rgb(im.at(u, v)), up_right = from_rgb(im.at(u + 1, v));
+    Color bot_left = from_rgb(im.at(u, v + 1)), bot_right = from_rgb(im.at(u + 1, v + 1));
+    double fu = sc.get_u_decimal(im.width - 1), fv = sc.get_v_decimal(im.height - 1);
+    return up_left * (1.0 - fu) * fv + up_right * fu * fv + bot_left * (1.0 - fu) * (1.0 - fv) + bot_right * fu * (1.0 - fv);
+}
+
+// src/geometry/matrix.rs:112-128
+inline M4 basis(V3 forward, V3 up) {
+    if (up == forward) up = v3(0.0, 0.0, -1.0);
+    V3 side = normalize(cross(forward, up));
+    ORC_ASSERT(length(side) - 1.0 < 0.0001);
+    up = normalize(cross(side, forward));
+    const double p[16] = {side.x, side.y, side.z, 0.0, up.x, up.y, up.z, 0.0, forward.x, forward.y, forward.z, 0.0, 0.0, 0.0, 0.0, 1.0};
+    return m4_from(p);
+}
+
+struct NormalMappable {
+    const Image* image = nullptr;
+    uint32_t kind = RT_NMAP_NORMAL;
+    double depth = 1.0;
+    double bump_height(uint32_t u, uint32_t v) const { return ((double)image->at(u, v)[0] / 255.0) * depth; }   // normal_map.rs:57-60
+    V3 get_normal(SurfaceCoord sc) const {
+        if (kind == RT_NMAP_NORMAL) {                                       // normal_map.rs:122-129
+            uint32_t u = sc.get_u_index(image->width), v = sc.get_v_index(image->height);
+            const uint8_t* p = image->at(u, v);
+            return normalize(v3((double)(128 - (int)p[0]), (double)(128 - (int)p[1]), (double)p[2]));
+        }
+        // BumpMap normal_map.rs:64-96
+        uint32_t u = sc.get_u_index(image->width - 1), v = sc.get_v_index(image->height - 1);
+        double up_left = bump_height(u, v), up_right = bump_height(u + 1, v);
+        double bot_left = bump_height(u, v + 1), bot_right = bump_height(u + 1, v + 1);
+        double fu = sc.get_u_decimal(image->width - 1), fv = sc.get_v_decimal(image->height - 1);
+        double up = fu * up_right + (1.0 - fu) * up_left;
+        double bot = fu * bot_right + (1.0 - fu) * bot_left;
+        double h = up - bot;
+        double h_denom = std::sqrt(h * h + 1.0);
+        V3 y_vec = v3(0.0, h / h_denom, 1.0 / h_denom);
+        double left = fv * up_left + (1.0 - fv) * bot_left;
+        double right = fv * up_right + (1.0 - fv) * bot_right;
+        h = right - left;
+        h_denom = std::sqrt(h * h + 1.0);
+        V3 x_vec = v3(h / h_denom, 0.0, 1.0 / h_denom);
+        V3 n = normalize(y_vec + x_vec);
+        ORC_ASSERT(length(n) - 1.0 < 0.00001);
+        return n;
+    }
+    V3 calculate_normal(SurfaceCoord sc, V3 old_normal, V3 up) const {     // normal_map.rs:10-12
+        return transform_vector(basis(old_normal, up), get_normal(sc));
+    }
+};
+
+// ---------------------------------------------------------------- Scene, shaders, lights
+struct Scene;
+struct Shadable {
+    uint32_t sid = 0;   // index in the scene description; keys the RNG path of spawned rays
+    virtual ~Shadable() = default;
+    virtual Color get_color(const Scene& scene, const Intersect& it) const = 0;
+    virtual Intersect modify_intersect(const Scene&, const Intersect& it) const { return it; }   // shader.rs:27-29
+};
+using ShaderPtr = std::shared_ptr<const Shadable>;
+
+struct Illum { bool lit; double surface_dot; V3 light_direction; Color intensity; };
+
+struct Lightable {
+    uint32_t index = 0;
+    virtual ~Lightable() = default;
+    virtual std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const = 0;
+};
+
+struct NodeIntersect { uint32_t hit_id; const Shadable* shader; Intersect intersect; };
+
+struct SceneNode {                                                          // scene.rs:142-148
+    uint32_t id = 0;
+    PrimPtr primitive;
+    ShaderPtr material;
+    Xform transform;
+    std::vector<std::unique_ptr<SceneNode>> children;
+
+    std::optional<NodeIntersect> trace(const Ray& ray_in) const {          // scene.rs:196-225
+        std::optional<NodeIntersect> fin;
+        Ray ray = ray_in.transform(transform.inv_trans);
+        if (primitive) {
+            tl_counters.instance_tests++;
+            if (auto it = primitive->get_closest_intersect(ray)) fin = NodeIntersect{id, material.get(), *it};
+        }
+        for (auto& child : children) {
+            if (auto c = child->trace(ray)) {
+                if (fin) {
+                    if (c->intersect.distance < fin->intersect.distance) fin = c;
+                } else fin = c;
+            }
+        }
+        if (fin) { fin->intersect = fin->intersect.transform(transform); return fin; }
+        return std::nullopt;
+    }
+    std::optional<NodeIntersect> partial_trace_until_distance(const Ray& ray_in, double max_distance) const {   // scene.rs:227-248
+        V3 max_distance_point = transform_point(transform.inv_trans, ray_in.point_at_distance(max_distance));
+        Ray ray = ray_in.transform(transform.inv_trans);
+        max_distance = length(ray.origin - max_distance_point);
+        if (primitive) {
+            tl_counters.instance_tests++;
+            if (auto it = primitive->get_closest_intersect(ray)) {
+                if (it->distance <= max_distance) return NodeIntersect{id, material.get(), it->transform(transform)};
+            }
+        }
+        for (auto& child : children) {
+            if (auto c = child->partial_trace_until_distance(ray, max_distance)) {
+                if (c->intersect.distance < max_distance) {
+                    c->intersect = c->intersect.transform(transform);
+                    return c;
+                }
+            }
+        }
+        return std::nullopt;
+    }
+};
+
+struct Scene {                                                              // scene.rs:47-53
+    std::unique_ptr<SceneNode> root;
+    std::vector<std::unique_ptr<Lightable>> lights;
+    Color ambient_color{0, 0, 0};
+    double ambient_power = 0;
+    bool has_background = false;
+    const Image* background_image = nullptr;
+    Xform background_transform;
+
+    Color ambient_intensity() const { return ambient_color * ambient_power; }   // light.rs:77-79
+    Color get_background_color(const Ray& ray_in) const {                   // scene.rs:99-106, 31-43
+        if (!has_background) return BLACK;
+        Ray ray = ray_in.transform(background_transform.inv_trans);
+        double azimuth = std::atan2(ray.direction.z, ray.direction.x);
+        double elevation = std::asin(ray.direction.y);
+        double u = (azimuth / 2.0) / PI + 0.5;
+        double v = elevation / PI + 0.5;
+        ORC_ASSERT(u >= 0.0 && u <= 1.0);
+        ORC_ASSERT(v >= 0.0 && v <= 1.0);
+        return texture_get_color(*background_image, SurfaceCoord::make(u, v));
+    }
+    static void count_ray(const Ray& ray) {
+        if (ray.path == 1) { if (tl_ray_class == 1) tl_counters.rays_aa++; else tl_counters.rays_primary++; }
+        else tl_counters.rays_secondary++;
+    }
+    Color cast_ray(const Ray& ray) const {                                  // scene.rs:66-74
+        if (ray.depth > 0 && ray.get_contribution() > Ray::MIN_CONTRIBUTION) {
+            count_ray(ray);
+            if (auto ni = root->trace(ray)) return ni->shader->get_color(*this, ni->intersect);
+        }
+        return get_background_color(ray);
+    }
+    struct Primary { double distance; Color color; uint32_t hit_id; };
+    Primary cast_ray_get_distance(const Ray& ray) const {                   // scene.rs:76-85
+        if (ray.depth > 0 && ray.get_contribution() > Ray::MIN_CONTRIBUTION) {
+            count_ray(ray);
+            if (auto ni = root->trace(ray)) return {ni->intersect.distance, ni->shader->get_color(*this, ni->intersect), ni->hit_id};
+        }
+        return {INF, get_background_color(ray), RT_NONE};
+    }
+};
+
+// ---- shaders
+struct PhongShader : Shadable {                                             // shader/phong.rs
+    Color diffuse, specular, ambient;
+    double shininess;
+    Color get_color(const Scene& scene, const Intersect& it) const override {   // :29-47
+        ORC_ASSERT(length(it.surface_normal) - 1.0 < 0.0001);
+        Color total = ambient * scene.ambient_intensity();
+        for (auto& light : scene.lights) {
+            for (auto& illum : light->get_illums_at(scene, it)) {
+                if (!illum.lit) continue;
+                tl_counters.shade_evals++;
+                V3 reflection_direction = normalize(2.0 * illum.surface_dot * it.surface_normal - illum.light_direction);
+                double specular_factor = std::pow(std::fmax(dot(reflection_direction, -1.0 * it.ray.direction), 0.0), shininess) / illum.surface_dot;
+                Color phong_color = specular * specular_factor + diffuse;
+                total += phong_color * illum.surface_dot * illum.intensity;
+            }
+        }
+        return total;
+    }
+};
+struct TextureShader : Shadable {                                           // shader/texture.rs:16-19
+    const Image* image;
+    Color get_color(const Scene&, const Intersect& it) const override { return texture_get_color(*image, it.surface_coord); }
+};
+struct ReflectionShader : Shadable {                                        // shader/reflection.rs:14-18
+    Color reflectivity;
+    Color get_color(const Scene& scene, const Intersect& it) const override {
+        Ray reflected = it.ray.reflect_off(it.hit_point, it.surface_normal).with_path(sid * 4 + 0);
+        return reflectivity * scene.cast_ray(reflected.contributes(reflectivity));
+    }
+};
+struct TranslucentShader : Shadable {                                       // shader/translucent.rs
+    Color translucency;
+    double refractive_index;
+    std::pair<double, double> get_fresnel(const Intersect& it) const {      // :19-46
+        double cosi = dot(it.ray.direction, it.surface_normal);
+        double etai = 1.0, etat = refractive_index;
+        if (cosi > 0.0) std::swap(etai, etat);
+        double sint = etai / etat * std::sqrt(std::fmax(1.0 - cosi * cosi, 0.0));
+        if (sint >= 1.0) return {0.0, 1.0};
+        double cost = std::sqrt(std::fmax(1.0 - sint * sint, 0.0));
+        cosi = std::fabs(cosi);
+        double rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+        double rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+        double reflectance = (rs * rs + rp * rp) * 0.5;
+        ORC_ASSERT(reflectance <= 1.0);
+        return {1.0 - reflectance, reflectance};
+    }
+    Color get_color(const Scene& scene, const Intersect& it) const override {   // :50-62
+        if (g_legacy_translucent) {
+            // The revision that rendered gallery/glass_monkey.png: the line still present as a
+            // comment at translucent.rs:59 — one transmitted ray, no Fresnel split.
+            Ray t = it.ray.transmit_through(it.hit_point, it.surface_normal, refractive_index).with_path(sid * 4 + 1);
+            return scene.cast_ray(t.contributes(translucency));
+        }
+        auto [kt, kr] = get_fresnel(it);
+        Ray reflected = it.ray.reflect_off(it.hit_point, it.surface_normal).with_path(sid * 4 + 2);
+        Ray transmitted = it.ray.transmit_through(it.hit_point, it.surface_normal, refractive_index).with_path(sid * 4 + 1);
+        Color color_t = kt > 0.0 ? scene.cast_ray(transmitted.contributes(WHITE * kt)) : BLACK;
+        Color color_r = kr > 0.0 ? scene.cast_ray(reflected.contributes(WHITE * kr)) : BLACK;
+        return (kr * color_r) + (kt * color_t);
+    }
+};
+struct MixShader : Shadable {                                               // shader.rs:66-69
+    std::vector<ShaderPtr> shaders;
+    Color get_color(const Scene& scene, const Intersect& it) const override {
+        Color acc = WHITE;
+        for (auto& s : shaders) acc = acc * s->get_color(scene, it.contributes(acc));
+        return acc;
+    }
+};
+struct CompositeShader : Shadable {                                         // shader.rs:95-102
+    std::vector<std::pair<double, ShaderPtr>> shaders;
+    Color get_color(const Scene& scene, const Intersect& it) const override {
+        Color total = BLACK;
+        for (auto& [w, s] : shaders) total += w * s->get_color(scene, it.contributes(w * WHITE));
+        return total;
+    }
+};
+struct ChainShader : Shadable {                                             // shader.rs:134-152
+    std::vector<ShaderPtr> shaders;
+    Color get_color(const Scene& scene, const Intersect& it) const override {
+        Intersect m = modify_intersect(scene, it);
+        return shaders.back()->get_color(scene, m);
+    }
+    Intersect modify_intersect(const Scene& scene, const Intersect& it) const override {
+        Intersect cur = it;
+        for (auto& s : shaders) cur = s->modify_intersect(scene, cur);
+        return cur;
+    }
+};
+struct NormalMapShader : Shadable {                                         // shader.rs:169-181
+    NormalMappable map;
+    Color get_color(const Scene&, const Intersect& it) const override {
+        V3 n = map.calculate_normal(it.surface_coord, it.surface_normal, it.surface_tangent);
+        return {n.x, n.y, n.z};
+    }
+    Intersect modify_intersect(const Scene&, const Intersect& it) const override {
+        Intersect r = it;
+        ORC_ASSERT(length(r.surface_normal) - 1.0 < 0.0001);
+        r.surface_normal = map.calculate_normal(it.surface_coord, it.surface_normal, it.surface_tangent);
+        ORC_ASSERT(length(r.surface_normal) - 1.0 < 0.0001);
+        return r;
+    }
+};
+
+// ---- lights (src/light.rs)
+inline bool shadowed(const Scene& scene, const Intersect& it, V3 light_direction, double light_distance) {
+    Ray shadow_ray = Ray::make(it.hit_point, light_direction, 1);           // :31, :263
+    tl_counters.rays_shadow++;
+    return scene.root->partial_trace_until_distance(shadow_ray, light_distance).has_value();
+}
+
+struct PointLight : Lightable {                                             // :122-148
+    V3 position; Color color; double power; double falloff[3];
+    Color get_intensity(double d) const { return power * color / (falloff[0] + falloff[1] * d + falloff[2] * d * d); }   // :145-147
+    std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const override {   // default impl :17-44, one sample
+        std::vector<Illum> ret;
+        V3 hit_to_light = position - it.hit_point;
+        V3 light_direction = normalize(hit_to_light);
+        double surface_dot = dot(light_direction, it.surface_normal);
+        if (surface_dot <= 0.0) { ret.push_back({false}); return ret; }
+        double light_distance = length(hit_to_light);
+        if (shadowed(scene, it, light_direction, light_distance)) ret.push_back({false});
+        else ret.push_back({true, surface_dot, light_direction, get_intensity(light_distance) / 1.0});
+        return ret;
+    }
+};
+
+struct DirectionLight : Lightable {                                         // :82-120
+    V3 direction; Color color; double power;
+    std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const override {
+        double surface_dot = dot(direction, it.surface_normal);
+        if (surface_dot <= 0.0) return {{false}};
+        Ray shadow_ray = Ray::make(it.hit_point, -1.0 * direction, 1);
+        tl_counters.rays_shadow++;
+        if (scene.root->trace(shadow_ray)) return {{false}};
+        return {{true, surface_dot, -1.0 * direction, color * power}};
+    }
+};
+
+struct SquareLight : Lightable {                                            // :151-375
+    V3 position; double size; Color color; double power; double inv_area;
+    static constexpr size_t SUB_DEPTH = 5;                                  // :187
+    Color get_intensity(double d) const { return color * power / (4.0 * PI * d * d); }   // :365-368
+
+    struct Rng {   // replaces thread_rng: draw #counter of (stream, path, light)
+        uint64_t stream; uint32_t path, light, counter;
+        double gen_range(double lo, double hi) { return lo + (hi - lo) * rng_light(stream, path, light, counter++); }
+    };
+    void subdivide_points(V2 min, V2 max, Rng& rng, V3 out[4]) const {      // :189-219
+        V2 change = max - min;
+        V2 low = min + change * 0.25, high = min + change * 0.75;
+        V2 left_high{low.x, low.y + change.y * 0.5}, right_low{low.x + change.x * 0.5, low.y};
+        V2 r = change * 0.25;
+        auto pt = [&](V2 c) {
+            double dx = rng.gen_range(-r.x, r.x);
+            double dz = rng.gen_range(-r.y, r.y);
+            return position + v3(c.x + dx, 0.0, c.y + dz);
+        };
+        out[0] = pt(left_high); out[1] = pt(high); out[2] = pt(low); out[3] = pt(right_low);
+    }
+    void guess_illums(V2 min, V2 max, const Intersect& it, size_t depth, double area_porp, Rng& rng, std::vector<Illum>& out) const {   // :222-245
+        size_t num_illums = (size_t)1 << (2 * depth);
+        area_porp = 4.0 * area_porp / (double)num_illums;
+        for (size_t i = 0; i < num_illums; ++i) {
+            double sx = rng.gen_range(min.x, max.x);
+            double sz = rng.gen_range(min.y, max.y);
+            V3 point = position + v3(sx, 0.0, sz);
+            V3 hit_to_light = point - it.hit_point;
+            double light_distance = length(hit_to_light);
+            V3 light_direction = hit_to_light / light_distance;
+            double surface_dot = dot(light_direction, it.surface_normal);
+            out.push_back({true, surface_dot, light_direction, get_intensity(light_distance) * area_porp});
+        }
+    }
+    void subdivide_illumination(V2 min, V2 max, const Scene& scene, const Intersect& it, size_t depth, Rng& rng, std::vector<Illum>& out) const {   // :248-298
+        Illum sample_illums[4];
+        V3 sample_points[4];
+        subdivide_points(min, max, rng, sample_points);
+        double area_porp = (max.x - min.x) * (max.y - min.y) * inv_area * 0.25;
+        size_t lit_count = 0;
+        for (int s = 0; s < 4; ++s) {
+            V3 hit_to_light = sample_points[s] - it.hit_point;
+            V3 light_direction = normalize(hit_to_light);
+            double surface_dot = dot(light_direction, it.surface_normal);
+            if (surface_dot <= 0.0) { sample_illums[s] = {false}; continue; }
+            double light_distance = length(hit_to_light);
+            if (shadowed(scene, it, light_direction, light_distance)) sample_illums[s] = {false};
+            else { sample_illums[s] = {true, surface_dot, light_direction, get_intensity(light_distance) * area_porp}; lit_count++; }
+        }
+        if (depth == 1 || lit_count == 0) {
+            for (auto& i : sample_illums) out.push_back(i);
+        } else if (depth > 1 && lit_count == 4) {
+            guess_illums(min, max, it, depth, area_porp, rng, out);
+        } else {
+            V2 change = (max - min) * 0.5;
+            V2 left{min.x, min.y + change.y}, mid = min + change, right{max.x, max.y - change.y};
+            V2 top{max.x - change.x, max.y}, bot{min.x + change.x, min.y};
+            subdivide_illumination(left, top, scene, it, depth - 1, rng, out);
+            subdivide_illumination(mid, max, scene, it, depth - 1, rng, out);
+            subdivide_illumination(min, mid, scene, it, depth - 1, rng, out);
+            subdivide_illumination(bot, right, scene, it, depth - 1, rng, out);
+        }
+    }
+    std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const override {   // :370-374
+        double half_size = size * 0.5;
+        Rng rng{it.ray.stream, it.ray.path, index, 0};
+        std::vector<Illum> out;
+        subdivide_illumination({-half_size, -half_size}, {half_size, half_size}, scene, it, SUB_DEPTH, rng, out);
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- scene construction from the flat description
+struct Built {
+    Scene scene;
+    std::vector<std::unique_ptr<Image>> images;
+};
+
+static std::unique_ptr<Built> build(const RtSceneDesc& d) {
+    std::call_once(g_gamma_once, init_gamma);
+    auto b = std::make_unique<Built>();
+    for (uint32_t i = 0; i < d.num_images; ++i) {
+        const RtImage& src = d.images[i];
+        auto im = std::make_unique<Image>();
+        im->width = src.width; im->height = src.height; im->channels = src.channels;
+        size_t row = (size_t)src.width * src.channels;
+        im->px.resize(row * src.height);
+        for (uint32_t y = 0; y < src.height; ++y)   // flip_vertical (texture.rs:46, normal_map.rs:52,116)
+            std::memcpy(&im->px[(size_t)y * row], d.texels + src.offset + (size_t)(src.height - 1 - y) * row, row);
+        b->images.push_back(std::move(im));
+    }
+    // primitives (plain ones first; wrappers and composites reference earlier or later entries → resolve lazily)
+    std::vector<PrimPtr> prims(d.num_prims);
+    std::vector<CsgPtr> csgs(d.num_csg);
+    std::function<PrimPtr(uint32_t)> get_prim;
+    std::function<CsgPtr(uint32_t)> get_csg;
+    auto make_plane = [&](const RtPrim& p) {
+        Plane pl;
+        pl.origin = v3(p.p[0], p.p[1], p.p[2]); pl.normal = v3(p.p[3], p.p[4], p.p[5]);
+        pl.tangent = v3(p.p[6], p.p[7], p.p[8]); pl.surface_scale = {p.p[9], p.p[10]};
+        return pl;
+    };
+    get_csg = [&](uint32_t i) -> CsgPtr {
+        if (csgs[i]) return csgs[i];
+        const RtCsgNode& n = d.csg[i];
+        if (n.kind == RT_CSG_BASE) {
+            auto s = std::make_shared<BaseShape>();
+            s->transform = Xform(m4_from(n.trans.m));
+            s->primitive = get_prim(n.prim);
+            csgs[i] = s;
+        } else {
+            auto s = std::make_shared<OpShape>();
+            s->kind = n.kind;
+            s->transform = Xform(m4_from(n.trans.m));
+            for (uint32_t k = 0; k < n.num_children; ++k) s->shapes.push_back(get_csg(d.csg_children[n.first_child + k]));
+            csgs[i] = s;
+        }
+        return csgs[i];
+    };
+    get_prim = [&](uint32_t i) -> PrimPtr {
+        if (prims[i]) return prims[i];
+        const RtPrim& p = d.prims[i];
+        switch (p.kind) {
+            case RT_PRIM_SPHERE: prims[i] = std::make_shared<Sphere>(p.p[0]); break;
+            case RT_PRIM_RECTANGLE: prims[i] = std::make_shared<Rectangle>(p.p[0], p.p[1]); break;
+            case RT_PRIM_PLANE: prims[i] = std::make_shared<Plane>(make_plane(p)); break;
+            case RT_PRIM_TRIANGLE:
+                prims[i] = std::make_shared<Triangle>(v3(p.p[0], p.p[1], p.p[2]), v3(p.p[3], p.p[4], p.p[5]), v3(p.p[6], p.p[7], p.p[8]));
+                break;
+            case RT_PRIM_POLYGON: {
+                std::vector<V3> v;
+                for (uint32_t k = 0; k < p.count; ++k) v.push_back(v3(d.points[(p.ref + k) * 3], d.points[(p.ref + k) * 3 + 1], d.points[(p.ref + k) * 3 + 2]));
+                prims[i] = std::make_shared<Polygon>(std::move(v));
+                break;
+            }
+            case RT_PRIM_CUBE: prims[i] = std::make_shared<Cube>(p.p[0]); break;
+            case RT_PRIM_TETRAHEDRON: prims[i] = std::make_shared<Tetrahedron>(p.p[0]); break;
+            case RT_PRIM_POLYHEDRON: {
+                auto ph = std::make_shared<Polyhedron>();
+                for (uint32_t k = 0; k < p.count; ++k) ph->planes.push_back(make_plane(d.prims[p.ref + k]));
+                prims[i] = ph;
+                break;
+            }
+            case RT_PRIM_ONEWAY: { auto w = std::make_shared<OneWay>(); w->primitive = get_prim(p.ref); prims[i] = w; break; }
+            case RT_PRIM_INVERTED: { auto w = std::make_shared<Inverted>(); w->primitive = get_prim(p.ref); prims[i] = w; break; }
+            case RT_PRIM_MESH: {
+                const RtMesh& m = d.meshes[p.ref];
+                auto mesh = std::make_shared<Mesh>();
+                for (uint32_t k = 0; k < m.num_positions; ++k) { const double* q = d.mesh_f64 + m.positions_off + 3 * (size_t)k; mesh->positions.push_back(v3(q[0], q[1], q[2])); }
+                for (uint32_t k = 0; k < m.num_normals; ++k) { const double* q = d.mesh_f64 + m.normals_off + 3 * (size_t)k; mesh->vertex_normals.push_back(v3(q[0], q[1], q[2])); }
+                for (uint32_t k = 0; k < m.num_texcoords; ++k) { const double* q = d.mesh_f64 + m.texcoords_off + 2 * (size_t)k; mesh->tex_coords.push_back({q[0], q[1]}); }
+                for (uint32_t k = 0; k < m.num_faces; ++k) { const uint32_t* q = d.mesh_u32 + m.faces_off + 3 * (size_t)k; mesh->faces.push_back({q[0], q[1], q[2]}); }
+                mesh->finish();
+                prims[i] = mesh;
+                break;
+            }
+            case RT_PRIM_CSG: prims[i] = get_csg(p.ref); break;
+        }
+        return prims[i];
+    };
+    // shaders
+    std::vector<ShaderPtr> shaders(d.num_shaders);
+    std::function<ShaderPtr(uint32_t)> get_shader = [&](uint32_t i) -> ShaderPtr {
+        if (shaders[i]) return shaders[i];
+        const RtShader& s = d.shaders[i];
+        std::shared_ptr<Shadable> out;
+        switch (s.kind) {
+            case RT_SHADER_PHONG: {
+                auto p = std::make_shared<PhongShader>();
+                p->diffuse = {s.p[0], s.p[1], s.p[2]}; p->specular = {s.p[3], s.p[4], s.p[5]}; p->ambient = {s.p[6], s.p[7], s.p[8]}; p->shininess = s.p[9];
+                out = p; break;
+            }
+            case RT_SHADER_TEXTURE: { auto p = std::make_shared<TextureShader>(); p->image = b->images[s.ref].get(); out = p; break; }
+            case RT_SHADER_REFLECTION: { auto p = std::make_shared<ReflectionShader>(); p->reflectivity = {s.p[0], s.p[1], s.p[2]}; out = p; break; }
+            case RT_SHADER_TRANSLUCENT: {
+                auto p = std::make_shared<TranslucentShader>(); p->translucency = {s.p[0], s.p[1], s.p[2]}; p->refractive_index = s.p[3]; out = p; break;
+            }
+            case RT_SHADER_MIX: {
+                auto p = std::make_shared<MixShader>();
+                for (uint32_t k = 0; k < s.num_children; ++k) p->shaders.push_back(get_shader(d.shader_child_idx[s.first_child + k]));
+                out = p; break;
+            }
+            case RT_SHADER_COMPOSITE: {
+                auto p = std::make_shared<CompositeShader>();
+                for (uint32_t k = 0; k < s.num_children; ++k)
+                    p->shaders.emplace_back(d.shader_child_weight[s.first_child + k], get_shader(d.shader_child_idx[s.first_child + k]));
+                out = p; break;
+            }
+            case RT_SHADER_CHAIN: {
+                auto p = std::make_shared<ChainShader>();
+                for (uint32_t k = 0; k < s.num_children; ++k) p->shaders.push_back(get_shader(d.shader_child_idx[s.first_child + k]));
+                out = p; break;
+            }
+            case RT_SHADER_NORMAL_MAP: {
+                auto p = std::make_shared<NormalMapShader>();
+                const RtNormalMap& nm = d.normal_maps[s.ref];
+                p->map.image = b->images[nm.image].get(); p->map.kind = nm.kind; p->map.depth = nm.depth;
+                out = p; break;
+            }
+        }
+        out->sid = i;
+        shaders[i] = out;
+        return out;
+    };
+    // node tree (DFS pre-order with subtree sizes)
+    std::function<std::unique_ptr<SceneNode>(uint32_t)> make_node = [&](uint32_t i) {
+        const RtNode& n = d.nodes[i];
+        auto node = std::make_unique<SceneNode>();
+        node->id = i;
+        if (n.prim != RT_NONE) node->primitive = get_prim(n.prim);
+        node->material = get_shader(n.shader);
+        node->transform = Xform(m4_from(n.trans.m));
+        for (uint32_t c = i + 1; c < i + n.subtree_size; c += d.nodes[c].subtree_size) node->children.push_back(make_node(c));
+        return node;
+    };
+    b->scene.root = make_node(0);
+    for (uint32_t i = 0; i < d.num_lights; ++i) {
+        const RtLight& l = d.lights[i];
+        std::unique_ptr<Lightable> out;
+        if (l.kind == RT_LIGHT_POINT) {
+            auto p = std::make_unique<PointLight>();
+            p->position = v3(l.position[0], l.position[1], l.position[2]); p->color = {l.color[0], l.color[1], l.color[2]};
+            p->power = l.power; std::memcpy(p->falloff, l.falloff, sizeof p->falloff);
+            out = std::move(p);
+        } else if (l.kind == RT_LIGHT_SQUARE) {
+            auto p = std::make_unique<SquareLight>();
+            p->position = v3(l.position[0], l.position[1], l.position[2]); p->color = {l.color[0], l.color[1], l.color[2]};
+            p->power = l.power; p->size = l.size; p->inv_area = 1.0 / (l.size * l.size);
+            out = std::move(p);
+        } else {
+            auto p = std::make_unique<DirectionLight>();
+            p->direction = v3(l.position[0], l.position[1], l.position[2]); p->color = {l.color[0], l.color[1], l.color[2]}; p->power = l.power;
+            out = std::move(p);
+        }
+        out->index = i;
+        b->scene.lights.push_back(std::move(out));
+    }
+    b->scene.ambient_color = {d.ambient_color[0], d.ambient_color[1], d.ambient_color[2]};
+    b->scene.ambient_power = d.ambient_power;
+    if (d.has_background) {
+        b->scene.has_background = true;
+        b->scene.background_image = b->images[d.background_image].get();
+        b->scene.background_transform = Xform(m4_from(d.background_trans.m));
+    }
+    return b;
+}
+
+// ---------------------------------------------------------------- ThreadPool (src/multithread.rs:21-98)
+class ThreadPool {
+public:
+    explicit ThreadPool(size_t n) {
+        for (size_t i = 0; i < n; ++i)
+            workers_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+                        if (jobs_.empty()) return;   // Terminate
+                        job = std::move(jobs_.front());
+                        jobs_.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    void execute(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(std::move(f)); }
+        cv_.notify_one();
+    }
+    ~ThreadPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+private:
+    std::vector<std::thread> workers_;
+    std::deque<std::function<void()>> jobs_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+inline uint32_t divide_round_up(uint32_t a, uint32_t b) { return (uint32_t)std::ceil((float)a / (float)b); }   // render.rs:356-358
+
+struct RowOwner {   // multi-rank split: row blocks of tile_rows rows, block b owned by rank b % nranks
+    uint32_t rank, nranks, tile_rows;
+    bool owns(uint32_t y) const { return nranks <= 1 || (y / tile_rows) % nranks == rank; }
+};
+
+// render_with_config (src/render.rs:99-312)
+static int render(const RtSceneDesc& desc, RtImageDim dim, const RtCamera& cc, const RtRenderConfig& rc, uint8_t* rgb_out, RtAux* aux) {
+    auto built = build(desc);
+    const Scene& scene = built->scene;
+    const uint32_t width = dim.width, height = dim.height;
+    RowOwner owner{rc.rank, rc.nranks ? rc.nranks : 1, rc.tile_rows ? rc.tile_rows : 16};
+
+    // camera basis :108-124
+    double aspect_ratio = (double)width / (double)height;
+    double fov_factor = std::tan(to_radians(cc.fov_y) / 2.0);
+    double x_factor = aspect_ratio * fov_factor;
+    V3 cam_origin = v3(cc.origin[0], cc.origin[1], cc.origin[2]);
+    V3 view_direction = normalize(v3(cc.target[0], cc.target[1], cc.target[2]) - cam_origin);
+    V3 side = normalize(cross(view_direction, v3(cc.up[0], cc.up[1], cc.up[2])));
+    V3 up = normalize(cross(side, view_direction));
+    const double cm[16] = {side.x, side.y, side.z, 0.0, up.x, up.y, up.z, 0.0,
+                           view_direction.x, view_direction.y, view_direction.z, 0.0, cam_origin.x, cam_origin.y, cam_origin.z, 1.0};
+    M4 camera_to_world = m4_from(cm);
+    auto calculate_pixel_location = [&](double x, double y) -> V3 {        // :127-132 (adds 0.5 again)
+        V4 r = m4_mul_v4(camera_to_world, {(2.0 * ((x + 0.5) / (double)width) - 1.0) * x_factor,
+                                           (1.0 - 2.0 * (y + 0.5) / (double)height) * fov_factor, 1.0, 1.0});
+        return v3(r.x, r.y, r.z);
+    };
+
+    struct Px { double distance; Color color; };
+    std::vector<Px> color_vec((size_t)width * height, Px{INF, BLACK});
+    std::vector<uint32_t> hit_ids((size_t)width * height, RT_NONE);
+    std::vector<uint8_t> need_row(height, 0);
+    for (uint32_t y = 0; y < height; ++y) {
+        if (!owner.owns(y)) continue;
+        need_row[y] = 1;
+        if (rc.anti_alias) { if (y > 0) need_row[y - 1] = 1; if (y + 1 < height) need_row[y + 1] = 1; }   // halo for the AA stencil
+    }
+    Counters total;
+    std::mutex total_mu;
+    {
+        ThreadPool pool(rc.num_threads ? rc.num_threads : 1);               // :147
+        uint32_t split = rc.workload_split ? rc.workload_split : 1;
+        uint32_t lines_per_chunk = divide_round_up(height, split);          // :152
+        for (uint32_t chunk = 0; chunk < split; ++chunk) {                  // :153-181
+            pool.execute([&, chunk] {
+                tl_counters = Counters{};
+                tl_ray_class = 0;
+                uint32_t y1 = std::min(height, (chunk + 1) * lines_per_chunk);
+                for (uint32_t y = chunk * lines_per_chunk; y < y1; ++y) {
+                    if (!need_row[y]) continue;
+                    for (uint32_t x = 0; x < width; ++x) {
+                        V3 pixel_location = calculate_pixel_location((double)x + 0.5, (double)y + 0.5);   // :167
+                        Ray prime_ray = Ray::from_destination(cam_origin, pixel_location, rc.recursion_depth);
+                        prime_ray.stream = rng_stream(rc.seed, (uint64_t)y * width + x, 0);
+                        auto r = scene.cast_ray_get_distance(prime_ray);
+                        color_vec[(size_t)y * width + x] = {r.distance, r.color};
+                        hit_ids[(size_t)y * width + x] = r.hit_id;
+                    }
+                }
+                std::lock_guard<std::mutex> lk(total_mu);
+                total.add(tl_counters);
+            });
+        }
+    }   // pool joins (Drop, multithread.rs:56-68)
+
+    std::vector<uint8_t> aa_mask((size_t)width * height, 0);
+    uint64_t aa_pixels = 0;
+    if (rc.anti_alias && width >= 3 && height >= 3) {                       // :202-308
+        static const int dirs[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
+        std::vector<std::pair<uint32_t, uint32_t>> aa_corrections;
+        for (uint32_t y = 1; y < height - 1; ++y) {
+            if (!owner.owns(y)) continue;
+            for (uint32_t x = 1; x < width - 1; ++x) {
+                int64_t ci = (int64_t)y * width + x;
+                const Px& c = color_vec[ci];
+                for (auto& d : dirs) {
+                    if (color_diff(c.color, color_vec[ci + d[0] * (int64_t)width + d[1]].color) > rc.aa_threshold && c.distance < INF) {
+                        aa_corrections.push_back({x, y});
+                        break;
+                    }
+                }
+            }
+        }
+        aa_pixels = aa_corrections.size();
+        double theta = 2.0 * PI / (double)rc.aa_rays;                       // :227
+        std::vector<Px> corrected(aa_corrections.size());
+        {
+            ThreadPool pool(rc.num_threads ? rc.num_threads : 1);
+            uint32_t split = rc.workload_split ? rc.workload_split : 1;
+            uint32_t per = divide_round_up((uint32_t)aa_corrections.size(), split);   // :230
+            for (uint32_t j = 0; j < split; ++j) {
+                size_t lo = (size_t)j * per, hi = std::min(aa_corrections.size(), (size_t)(j + 1) * per);
+                if (lo >= hi) continue;
+                pool.execute([&, lo, hi] {
+                    tl_counters = Counters{};
+                    tl_ray_class = 1;
+                    for (size_t k = lo; k < hi; ++k) {                      // :259-299
+                        uint32_t x = aa_corrections[k].first, y = aa_corrections[k].second;
+                        uint64_t pixel = (uint64_t)y * width + x;
+                        const Px& orig = color_vec[pixel];
+                        uint64_t stream0 = rng_stream(rc.seed, pixel, 0);
+                        Color total_color = BLACK;
+                        total_color += orig.color;
+                        double rand_rotation = 0.0 + (2.0 * PI - 0.0) * rng_aa(stream0, 0);   // gen_range(0, 2π) :266
+                        for (uint32_t i = 0; i < rc.aa_rays; ++i) {
+                            double dx = std::cos(rand_rotation + theta * (double)i);
+                            double dy = std::sin(rand_rotation + theta * (double)i);
+                            double rand_distance = 0.2 + (0.5 - 0.2) * rng_aa(stream0, 1 + i);   // gen_range(0.2, 0.5) :277
+                            double x_pos = (double)x + 0.5 + dx * rand_distance;
+                            double y_pos = (double)y + 0.5 + dy * rand_distance;
+                            V3 pixel_location = calculate_pixel_location(x_pos, y_pos);
+                            Ray prime_ray = Ray::from_destination(cam_origin, pixel_location, rc.recursion_depth);
+                            prime_ray.stream = rng_stream(rc.seed, pixel, 1 + i);
+                            // correction.2 != INFINITY always holds for flagged pixels (:284-289)
+                            total_color += scene.cast_ray(prime_ray);
+                        }
+                        corrected[k] = {0.0, total_color / (double)(rc.aa_rays + 1)};   // :297, :306
+                    }
+                    std::lock_guard<std::mutex> lk(total_mu);
+                    total.add(tl_counters);
+                });
+            }
+        }
+        for (size_t k = 0; k < aa_corrections.size(); ++k) {
+            size_t idx = (size_t)aa_corrections[k].second * width + aa_corrections[k].first;
+            color_vec[idx] = corrected[k];
+            aa_mask[idx] = 1;
+        }
+    }
+
+    // make_image :361-370
+    for (uint32_t y = 0; y < height; ++y) {
+        for (uint32_t x = 0; x < width; ++x) {
+            size_t i = (size_t)y * width + x;
+            bool mine = owner.owns(y);
+            Color c = color_clamp(color_vec[i].color);
+            if (rgb_out) {
+                rgb_out[3 * i + 0] = mine ? encode_channel(c.r) : 0;
+                rgb_out[3 * i + 1] = mine ? encode_channel(c.g) : 0;
+                rgb_out[3 * i + 2] = mine ? encode_channel(c.b) : 0;
+            }
+            if (aux && mine) {
+                if (aux->color) { aux->color[3 * i] = color_vec[i].color.r; aux->color[3 * i + 1] = color_vec[i].color.g; aux->color[3 * i + 2] = color_vec[i].color.b; }
+                if (aux->distance) aux->distance[i] = color_vec[i].distance;
+                if (aux->hit_id) aux->hit_id[i] = hit_ids[i];
+                if (aux->aa_mask) aux->aa_mask[i] = aa_mask[i];
+            }
+        }
+    }
+    if (aux) {
+        RtCounters& c = aux->counters;
+        std::memset(&c, 0, sizeof c);
+        c.rays_primary = total.rays_primary; c.rays_secondary = total.rays_secondary; c.rays_shadow = total.rays_shadow;
+        c.rays_aa = total.rays_aa; c.aa_pixels = aa_pixels; c.instance_tests = total.instance_tests; c.box_tests = total.box_tests;
+        c.tri_tests = total.tri_tests; c.shade_evals = total.shade_evals;
+        c._reserved[0] = total.assert_failures;
+    }
+    return RT_OK;
+}
+
+}  // namespace orc
+
+extern "C" {
+
+// Same contract as rt_render (include/rt_amd.h), executed by the CPU restatement.
+// counters._reserved[0] returns the number of reference `assert!`s that would have fired.
+int oracle_render(const RtSceneDesc* desc, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg,
+                  uint8_t* rgb_out, RtAux* aux) {
+    if (!desc || !dim || !cam || !cfg || dim->width == 0 || dim->height == 0 || desc->num_nodes == 0) return RT_ERR_INVALID_ARG;
+    if (cfg->interactive) return RT_ERR_UNSUPPORTED;
+    return orc::render(*desc, *dim, *cam, *cfg, rgb_out, aux);
+}
+
+// 1: recompute the 4x4 inverse in every Intersect::transform like the reference does
+// (used for the CPU-baseline timing); 0: use the cached, bit-identical value.
+void oracle_set_faithful_cost(int on) { orc::g_recompute_inverse = on != 0; }
+
+// Diagnostic: 1 = meshes test every face instead of walking the kd-tree (exact closest hit).
+// 1: TranslucentShader casts only the transmitted ray, weighted by `translucency`, the
+// behaviour of the reference revision that produced gallery/glass_monkey.png (today a
+// commented-out line, src/shader/translucent.rs:59).  Used only to pin the oracle
+// against that image.
+void oracle_set_legacy_translucent(int on) { orc::g_legacy_translucent = on != 0; }
+void oracle_set_mesh_brute_force(int on) { orc::g_mesh_brute_force = on != 0; }
+
+}  // extern "C"
