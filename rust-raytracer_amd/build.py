@@ -1,0 +1,60 @@
+"""Builds the native pieces in-tree (the .so files travel to the GPU box with the tree).
+
+  csrc/librt_amd.so            HIP render path for gfx950 (hipcc cross-compiles without a GPU)
+  host/libraytracer_host.so    C++ mirror of the reference API + the transcribed test scenes
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(HERE, "csrc", "librt_amd.so")
+HOST_LIB = os.path.join(HERE, "host", "libraytracer_host.so")
+
+# -ffp-contract=off keeps the device arithmetic un-fused like the reference's (Rust never
+# contracts a*b+c); RT_FP_CONTRACT=fast trades that for FMA throughput.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+             "-ffp-contract=" + os.environ.get("RT_FP_CONTRACT", "off")]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_hip(force=False):
+    src_dir = os.path.join(HERE, "csrc")
+    sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".hpp"))]
+    sources.append(os.path.join(INCLUDE, "rt_amd.h"))
+    if force or _newer(HIP_LIB, sources):
+        _run(["hipcc", *HIP_FLAGS, "-I" + INCLUDE, "-o", HIP_LIB, os.path.join(src_dir, "rt_api.hip")])
+    return HIP_LIB
+
+
+def build_host(force=False):
+    src_dir = os.path.join(HERE, "host")
+    sources = [os.path.join(src_dir, f) for f in ("raytracer.cpp", "scenes.cpp", "raytracer.hpp")]
+    sources.append(os.path.join(INCLUDE, "rt_amd.h"))
+    if force or _newer(HOST_LIB, sources):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + INCLUDE, "-o", HOST_LIB,
+              os.path.join(src_dir, "raytracer.cpp"), os.path.join(src_dir, "scenes.cpp")])
+    return HOST_LIB
+
+
+def build_all(force=False):
+    build_host(force)
+    build_hip(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

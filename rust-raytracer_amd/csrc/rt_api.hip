@@ -1,0 +1,374 @@
+// rt_api.hip — C ABI of the MI355X render path (include/rt_amd.h): scene upload,
+// frame driver, error reporting.  The frame driver replaces render_with_config
+// (src/render.rs:99-312); the scene upload replaces the per-job `scene.clone()`
+// (src/render.rs:158,237) by one immutable device copy.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_flatten.hpp"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+template <class T>
+int upload(const std::vector<T>& v, std::vector<void*>& owned, const T** out) {
+    *out = nullptr;
+    if (v.empty()) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    owned.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+}  // namespace
+
+struct RtScene {
+    int device = 0;
+    int num_cus = 256;
+    DScene ds{};
+    std::vector<void*> owned;
+    uint32_t max_spawn = 0;
+    // per-frame workspace, grown on demand and reused across frames
+    std::mutex mu;
+    DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
+    std::vector<uint32_t> rows_host;
+    uint32_t rows_key[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+};
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->owned) (void)hipFree(p);
+    for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full}) b->release();
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARG, "device index out of range");
+    rtflat::FlatScene fs;
+    try {
+        rtflat::flatten(*desc, fs);
+    } catch (const rtflat::Unsupported& e) {
+        return fail(RT_ERR_UNSUPPORTED, e.what());
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID_ARG, e.what());
+    }
+    HIP_TRY(hipSetDevice(device));
+    RtScene* s = new (std::nothrow) RtScene();
+    if (!s) return fail(RT_ERR_DEVICE, "out of host memory");
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
+    DScene& d = s->ds;
+    int rc = RT_OK;
+#define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
+    UP(instances, fs.instances); UP(prims, fs.prims); UP(tris, fs.tris); UP(polys, fs.polys); UP(points, fs.points);
+    UP(faced, fs.faced); UP(meshes, fs.meshes); UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris);
+    UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(csg_roots, fs.csg_roots); UP(csg_ops, fs.csg_ops);
+    UP(csg_leaves, fs.csg_leaves); UP(shaders, fs.shaders); UP(shader_child_idx, fs.shader_child_idx);
+    UP(shader_child_weight, fs.shader_child_weight); UP(chain_nmaps, fs.chain_nmaps); UP(normal_maps, fs.normal_maps);
+    UP(images, fs.images); UP(texels, fs.texels); UP(gamma_lut, fs.gamma_lut); UP(lights, fs.lights);
+#undef UP
+    if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+    d.num_instances = (uint32_t)fs.instances.size();
+    d.num_lights = (uint32_t)fs.lights.size();
+    std::memcpy(d.ambient, fs.ambient, sizeof d.ambient);
+    d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
+    for (auto& e : s->ev)
+        if (hipEventCreate(&e) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    *out = s;
+    return RT_OK;
+}
+
+uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_rows) {
+    if (tile_rows == 0) tile_rows = 16;
+    if (nranks <= 1) return height;
+    uint32_t blocks = (height + tile_rows - 1) / tile_rows;
+    return ((blocks + nranks - 1) / nranks) * tile_rows;
+}
+
+}  // extern "C"
+
+namespace {
+
+int check_args(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg) {
+    if (!scene || !dim || !cam || !cfg) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    if (dim->width == 0 || dim->height == 0) return fail(RT_ERR_INVALID_ARG, "rt_render: empty image");
+    if ((uint64_t)dim->width * dim->height > 0x7FFFFFFFull / 8) return fail(RT_ERR_CAPACITY, "rt_render: image larger than 2^28 pixels");
+    if (cfg->interactive) return fail(RT_ERR_UNSUPPORTED, "rt_render: interactive mode is not part of the render path");
+    if (cfg->nranks > 1 && cfg->rank >= cfg->nranks) return fail(RT_ERR_INVALID_ARG, "rt_render: rank >= nranks");
+    if (cfg->anti_alias && cfg->aa_rays == 0) return fail(RT_ERR_INVALID_ARG, "rt_render: anti_alias with aa_rays == 0");
+    if (cfg->anti_alias && cfg->aa_rays > 64) return fail(RT_ERR_CAPACITY, "rt_render: aa_rays > 64");
+    return RT_OK;
+}
+
+// The whole frame, enqueued on `stream`.  Device-resident results: s->color / distance /
+// hit_id / mask (full W*H arrays) and `d_rgb` (owned rows).
+int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const RtRenderConfig& rc, uint8_t* d_rgb,
+                  bool count_work, hipStream_t stream) {
+    const uint32_t W = dim.width, H = dim.height;
+    const size_t npix = (size_t)W * H;
+    DRenderParams rp{};
+    // camera basis, src/render.rs:108-124
+    {
+        double aspect_ratio = (double)W / (double)H;
+        double fov_factor = std::tan((cc.fov_y * (M_PI / 180.0)) / 2.0);
+        rp.cam.x_factor = aspect_ratio * fov_factor;
+        rp.cam.fov_factor = fov_factor;
+        auto norm = [](double* v) { double inv = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= inv; v[1] *= inv; v[2] *= inv; };
+        auto cross = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+        double view[3] = {cc.target[0] - cc.origin[0], cc.target[1] - cc.origin[1], cc.target[2] - cc.origin[2]};
+        norm(view);
+        double side[3]; cross(view, cc.up, side); norm(side);
+        double up[3]; cross(side, view, up); norm(up);
+        std::memcpy(rp.cam.origin, cc.origin, sizeof rp.cam.origin);
+        std::memcpy(rp.cam.side, side, sizeof side); std::memcpy(rp.cam.up, up, sizeof up); std::memcpy(rp.cam.view, view, sizeof view);
+        rp.cam.width = W; rp.cam.height = H;
+    }
+    rp.recursion_depth = rc.recursion_depth; rp.aa_rays = rc.aa_rays; rp.aa_threshold = rc.aa_threshold; rp.seed = rc.seed;
+    rp.rank = rc.rank; rp.nranks = rc.nranks ? rc.nranks : 1; rp.tile_rows = rc.tile_rows ? rc.tile_rows : 16;
+
+    // rows this rank renders: owned row blocks plus the AA halo
+    uint32_t key[5] = {W, H, rp.rank, rp.nranks, rp.tile_rows * 2 + (rc.anti_alias ? 1u : 0u)};
+    if (std::memcmp(key, s->rows_key, sizeof key) != 0 || s->rows_host.empty()) {
+        std::vector<uint8_t> need(H, 0);
+        for (uint32_t y = 0; y < H; ++y) {
+            bool mine = rp.nranks <= 1 || (y / rp.tile_rows) % rp.nranks == rp.rank;
+            if (!mine) continue;
+            need[y] = 1;
+            if (rc.anti_alias && rp.nranks > 1) { if (y > 0) need[y - 1] = 1; if (y + 1 < H) need[y + 1] = 1; }
+        }
+        s->rows_host.clear();
+        for (uint32_t y = 0; y < H; ++y) if (need[y]) s->rows_host.push_back(y);
+        int e = s->rows.ensure(std::max<size_t>(1, s->rows_host.size()) * sizeof(uint32_t));
+        if (e != RT_OK) return e;
+        if (!s->rows_host.empty()) HIP_TRY(hipMemcpyAsync(s->rows.p, s->rows_host.data(), s->rows_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // rows_host may be rewritten by the next call
+        std::memcpy(s->rows_key, key, sizeof key);
+    }
+    const uint32_t num_rows = (uint32_t)s->rows_host.size();
+
+    int e;
+    if ((e = s->color.ensure(npix * 3 * sizeof(double))) != RT_OK) return e;
+    if ((e = s->distance.ensure(npix * sizeof(double))) != RT_OK) return e;
+    if ((e = s->hit_id.ensure(npix * sizeof(uint32_t))) != RT_OK) return e;
+    if ((e = s->mask.ensure(npix)) != RT_OK) return e;
+    if ((e = s->scalars.ensure(256 + sizeof(DCounters))) != RT_OK) return e;
+    unsigned int* next_tile = static_cast<unsigned int*>(s->scalars.p);          // [0]
+    unsigned int* aa_count = next_tile + 1;                                       // [1]
+    unsigned int* next_chunk = next_tile + 2;                                     // [2]
+    DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(s->scalars.p) + 256);
+    HIP_TRY(hipMemsetAsync(s->scalars.p, 0, 256 + sizeof(DCounters), stream));
+    HIP_TRY(hipMemsetAsync(s->mask.p, 0, npix, stream));
+    if (rp.nranks > 1) {   // rows never rendered by this rank must not look like data
+        HIP_TRY(hipMemsetAsync(s->color.p, 0, npix * 3 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(s->distance.p, 0, npix * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(s->hit_id.p, 0xFF, npix * sizeof(uint32_t), stream));
+    }
+
+    // persistent grid: enough waves to fill every CU several times over; each pulls tiles until none are left
+    const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
+    const uint32_t max_waves = (uint32_t)s->num_cus * 16;
+    HIP_TRY(hipEventRecord(s->ev[0], stream));
+    if (num_rows > 0) {
+        uint32_t grid = std::min(tiles, max_waves);
+        if (count_work)
+            hipLaunchKernelGGL(k_pass1<true>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->rows.p, num_rows,
+                               (double*)s->color.p, (double*)s->distance.p, (uint32_t*)s->hit_id.p, next_tile, counters);
+        else
+            hipLaunchKernelGGL(k_pass1<false>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->rows.p, num_rows,
+                               (double*)s->color.p, (double*)s->distance.p, (uint32_t*)s->hit_id.p, next_tile, counters);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s->ev[1], stream));
+    if (rc.anti_alias && W >= 3 && H >= 3 && num_rows > 0) {
+        // worst case every owned interior pixel is flagged
+        size_t owned_px = (size_t)W * num_rows;
+        if ((e = s->list.ensure(owned_px * sizeof(uint32_t))) != RT_OK) return e;
+        if ((e = s->samples.ensure(owned_px * rc.aa_rays * 3 * sizeof(double))) != RT_OK) return e;
+        uint32_t blocks = (uint32_t)((npix + 255) / 256);
+        hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, (const double*)s->distance.p,
+                           (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
+        HIP_TRY(hipGetLastError());
+        uint32_t grid = max_waves;
+        if (count_work)
+            hipLaunchKernelGGL(k_aa_resolve<true>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->list.p, aa_count,
+                               (double*)s->samples.p, next_chunk, counters);
+        else
+            hipLaunchKernelGGL(k_aa_resolve<false>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->list.p, aa_count,
+                               (double*)s->samples.p, next_chunk, counters);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
+                           (const double*)s->samples.p, (double*)s->color.p, (double*)s->distance.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s->ev[2], stream));
+    if (d_rgb) {
+        uint32_t blocks = (uint32_t)((npix + 255) / 256);
+        hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, d_rgb);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s->ev[3], stream));
+    s->timed = true;
+    return RT_OK;
+}
+
+void fill_counters(RtCounters& out, const DCounters& c) {
+    std::memset(&out, 0, sizeof out);
+    out.rays_primary = c.rays_primary; out.rays_secondary = c.rays_secondary; out.rays_shadow = c.rays_shadow; out.rays_aa = c.rays_aa;
+    out.aa_pixels = c.aa_pixels; out.instance_tests = c.instance_tests; out.box_tests = c.box_tests; out.tri_tests = c.tri_tests;
+    out.shade_evals = c.shade_evals; out.stack_overflows = c.stack_overflows;
+    // Algorithmic f64 flop estimate: fixed cost per unit of counted work —
+    // ray→instance transform + analytic primitive test 48, BVH box slab test 24, mesh triangle
+    // test 60, Phong per lit sample 40, hit→world + shading set-up 45 per closest-hit ray,
+    // reflect/refract/Fresnel 30 per secondary ray.
+    out.flops = 48 * c.instance_tests + 24 * c.box_tests + 60 * c.tri_tests + 40 * c.shade_evals +
+                45 * (c.rays_primary + c.rays_secondary + c.rays_aa) + 30 * c.rays_secondary;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg,
+                     uint8_t* d_rgb_out, RtAux* d_aux, void* hip_stream) {
+    int rc = check_args(scene, dim, cam, cfg);
+    if (rc != RT_OK) return rc;
+    RtScene* s = const_cast<RtScene*>(scene);
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    bool count = d_aux && d_aux->count_work;
+    rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, count, stream);
+    if (rc != RT_OK) return rc;
+    if (d_aux) {
+        const size_t npix = (size_t)dim->width * dim->height;
+        if (d_aux->color) HIP_TRY(hipMemcpyAsync(d_aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->distance) HIP_TRY(hipMemcpyAsync(d_aux->distance, s->distance.p, npix * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->hit_id) HIP_TRY(hipMemcpyAsync(d_aux->hit_id, s->hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->aa_mask) HIP_TRY(hipMemcpyAsync(d_aux->aa_mask, s->mask.p, npix, hipMemcpyDeviceToDevice, stream));
+        if (count) {   // counters are host-visible results: this variant of the call synchronises
+            DCounters c{};
+            unsigned int aa = 0;
+            HIP_TRY(hipMemcpyAsync(&c, static_cast<char*>(s->scalars.p) + 256, sizeof c, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + 4, sizeof aa, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            c.aa_pixels = aa;
+            fill_counters(d_aux->counters, c);
+        }
+    }
+    return RT_OK;
+}
+
+int rt_last_timings(const RtScene* scene, double* ms_pass1, double* ms_aa, double* ms_encode) {
+    if (!scene) return fail(RT_ERR_INVALID_ARG, "rt_last_timings: null scene");
+    RtScene* s = const_cast<RtScene*>(scene);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->timed) return fail(RT_ERR_INVALID_ARG, "rt_last_timings: no frame rendered yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev[3]));
+    float a = 0, b = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&c, s->ev[2], s->ev[3]));
+    if (ms_pass1) *ms_pass1 = a;
+    if (ms_aa) *ms_aa = b;
+    if (ms_encode) *ms_encode = c;
+    return RT_OK;
+}
+
+int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg,
+              uint8_t* rgb_out, RtAux* aux) {
+    int rc = check_args(scene, dim, cam, cfg);
+    if (rc != RT_OK) return rc;
+    if (!rgb_out) return fail(RT_ERR_INVALID_ARG, "rt_render: rgb_out is null");
+    RtScene* s = const_cast<RtScene*>(scene);
+    const size_t npix = (size_t)dim->width * dim->height;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        HIP_TRY(hipSetDevice(s->device));
+        uint32_t rows_cap = rt_owned_rows_capacity(dim->height, cfg->nranks, cfg->tile_rows);
+        size_t rgb_bytes = (size_t)rows_cap * dim->width * 3;
+        int e = s->rgb_full.ensure(rgb_bytes);
+        if (e != RT_OK) return e;
+        HIP_TRY(hipMemsetAsync(s->rgb_full.p, 0, rgb_bytes, nullptr));
+        bool count = aux && aux->count_work;
+        rc = enqueue_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
+        if (rc != RT_OK) return rc;
+        HIP_TRY(hipMemcpy(rgb_out, s->rgb_full.p, rgb_bytes, hipMemcpyDeviceToHost));
+        if (aux) {
+            if (aux->color) HIP_TRY(hipMemcpy(aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
+            if (aux->distance) HIP_TRY(hipMemcpy(aux->distance, s->distance.p, npix * sizeof(double), hipMemcpyDeviceToHost));
+            if (aux->hit_id) HIP_TRY(hipMemcpy(aux->hit_id, s->hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (aux->aa_mask) HIP_TRY(hipMemcpy(aux->aa_mask, s->mask.p, npix, hipMemcpyDeviceToHost));
+            DCounters c{};
+            unsigned int aa = 0;
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + 256, sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + 4, sizeof aa, hipMemcpyDeviceToHost));
+            c.aa_pixels = aa;
+            fill_counters(aux->counters, c);
+        }
+    }
+    if (aux) {
+        double a = 0, b = 0, c = 0;
+        if (rt_last_timings(scene, &a, &b, &c) == RT_OK) { aux->ms_pass1 = a; aux->ms_aa = b; aux->ms_encode = c; }
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// rt_device_types.h — flat, device-resident scene layout shared by the host-side
+// flattening (rt_flatten.hpp) and the kernels (rt_kernels.hip).
+//
+// The reference walks a tree of boxed trait objects per ray (src/scene.rs:196-225).
+// Here the tree is flattened once per scene into arrays of PODs that live in HBM for
+// the lifetime of the RtScene and are read-only during rendering:
+//   instances[]  one per SceneNode that owns a primitive, with the composed
+//                world<->local transforms of all its ancestors
+//   prims[]      analytic primitives (+ wrapper chain), tris[], faced[], planes
+//   meshes[]     per mesh: BVH nodes + triangle records + vertex attributes
+//   csg_*        composite shapes as a postfix program over transformed leaves
+//   shaders[]    the shader tree, walked by a small interpreter per hit
+//   lights[], images[] + texel blob, normal maps, gamma table
+#pragma once
+#include <stdint.h>
+
+#define RT_MAX_STACK 64        // secondary-ray stack entries per camera sample
+#define RT_BVH_STACK 48        // BVH traversal stack entries
+#define RT_CSG_MAX_HITS 16     // hits per composite-shape list
+#define RT_CSG_ARENA 96        // hits across all live lists of one composite query
+#define RT_CSG_MAX_LISTS 12
+#define RT_SHADE_MAX_FRAMES 8  // nesting depth of group shaders
+#define RT_SHADE_MAX_SPAWN 8   // secondary rays one hit may spawn
+
+struct DAffine {               // y = R x + t, rows of R in r[0..3), r[4..7), r[8..11) with t at r[3], r[7], r[11]
+    double r[12];
+};
+
+struct DXform {
+    DAffine w2l;               // parent/world → local
+    DAffine l2w;               // local → parent/world
+    double nmat[9];            // normals: n_world ∝ nmat * n_local  (= transpose of the linear part of w2l)
+    double uniform_inv_s;      // 1/|w2l_lin d| for unit d when the scale is uniform, else 0
+    double uniform_s;          // |w2l_lin d| for unit d when the scale is uniform, else 0
+};
+
+enum DPrimKind {
+    DP_SPHERE = 0, DP_RECTANGLE, DP_PLANE, DP_TRIANGLE, DP_POLYGON, DP_FACED, DP_POLYHEDRON, DP_MESH, DP_CSG
+};
+enum { DWRAP_NONE = 0, DWRAP_ONEWAY = 1, DWRAP_INVERTED = 2 };
+
+struct DPrim {
+    uint32_t kind;
+    uint32_t ref;              // TRIANGLE: tris[]; POLYGON: polys[]; FACED: faced[]; POLYHEDRON: first plane prim; MESH: meshes[]; CSG: csg_roots[]
+    uint32_t count;            // POLYHEDRON: number of planes
+    uint32_t wrap;             // wrapper chain, 2 bits per level, innermost first
+    double p[12];              // SPHERE r; RECTANGLE w,h; PLANE origin,normal,tangent,scale
+};
+
+struct DTri {                  // primitive::Triangle with its constructor-derived fields (plane.rs:111-126)
+    double v[9], e[9], n[3], tangent[3];
+    double sc_width, sc_height, side_c;
+};
+
+struct DPoly {                 // primitive::Polygon: projected vertices and edges live in points[] (plane.rs:181-202)
+    uint32_t first_vertex, first_edge, count, _pad;
+    double n[3];
+};
+
+struct DFaced {                // Cube (6 rectangles) / Tetrahedron (4 triangles): cube.rs
+    uint32_t nfaces, base_is_triangle, base_tri, is_cube;
+    double base_w, base_h;     // rectangle base
+    DXform face[6];
+};
+
+struct DBvhNode {              // binary BVH; both children's boxes are stored in the parent
+    double lo[2][3], hi[2][3];
+    uint32_t child[2];         // bit 31 set: leaf, low bits = first triangle; else node index
+    uint32_t count[2];         // leaf: triangle count
+};
+
+struct DMeshTri {              // one mesh face in BVH order (mesh.rs:416-466 inputs)
+    double v1[3], v2[3], v3[3], n[3];
+    double inv_area;
+    uint32_t i1, i2, i3, face;
+};
+
+struct DMesh {
+    uint32_t node_off, tri_off, num_tris, num_nodes;
+    uint32_t normal_off, uv_off;   // into mesh_normals (3/vertex) and mesh_uvs (2/vertex)
+    uint32_t num_normals, num_uvs;
+    double lo[3], hi[3];
+};
+
+enum DCsgKind { DC_BASE = 0, DC_SUBTRACT, DC_AND, DC_OR, DC_XOR, DC_MULTI_AND };
+struct DCsgOp {                // postfix program: children precede their parent
+    uint32_t kind, num_children, leaf, _pad;
+};
+struct DCsgLeaf {
+    DXform x;                  // composite-root parent space ↔ leaf primitive space
+    uint32_t prim, _pad;
+};
+struct DCsgRoot { uint32_t op_begin, op_count; };
+
+enum DShaderKind { DS_PHONG = 0, DS_TEXTURE, DS_REFLECTION, DS_TRANSLUCENT, DS_MIX, DS_COMPOSITE, DS_CHAIN, DS_NORMAL_MAP };
+struct DShader {
+    uint32_t kind, ref, first_child, num_children;
+    uint32_t nm_begin, nm_count;   // CHAIN: normal maps applied (in order) by modify_intersect
+    double p[10];
+};
+
+struct DNormalMap { uint32_t kind, image; double depth; };
+struct DImage { uint32_t width, height, channels, _pad; uint64_t offset; };
+
+struct DLight {
+    uint32_t kind, index;
+    double position[3], color[3], power, falloff[3], size, inv_area;
+};
+
+struct DInstance {
+    DXform x;
+    uint32_t prim, shader, node_id, is_root;
+};
+
+struct DScene {
+    const DInstance* instances;  uint32_t num_instances;
+    const DPrim* prims;
+    const DTri* tris;
+    const DPoly* polys;
+    const double* points;
+    const DFaced* faced;
+    const DMesh* meshes;
+    const DBvhNode* bvh_nodes;
+    const DMeshTri* mesh_tris;
+    const double* mesh_normals;
+    const double* mesh_uvs;
+    const DCsgRoot* csg_roots;
+    const DCsgOp* csg_ops;
+    const DCsgLeaf* csg_leaves;
+    const DShader* shaders;
+    const uint32_t* shader_child_idx;
+    const double* shader_child_weight;
+    const uint32_t* chain_nmaps;
+    const DNormalMap* normal_maps;
+    const DImage* images;
+    const uint8_t* texels;       // rows already flipped vertically (texture.rs:46)
+    const double* gamma_lut;     // 256 entries: (i/255)^2.2
+    const DLight* lights;        uint32_t num_lights;
+    double ambient[3];           // ambient colour * power
+    uint32_t has_background, background_image;
+    DAffine background_w2l;
+};
+
+struct DCamera {
+    double origin[3], side[3], up[3], view[3];
+    double x_factor, fov_factor;
+    uint32_t width, height;
+};
+
+struct DRenderParams {
+    DCamera cam;
+    uint32_t recursion_depth, aa_rays;
+    double aa_threshold;
+    uint64_t seed;
+    uint32_t rank, nranks, tile_rows, _pad;
+};
+
+struct DCounters {             // mirrors RtCounters' first ten fields
+    unsigned long long rays_primary, rays_secondary, rays_shadow, rays_aa, aa_pixels,
+        instance_tests, box_tests, tri_tests, shade_evals, stack_overflows;
+};

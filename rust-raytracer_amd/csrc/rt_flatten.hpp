@@ -1,0 +1,597 @@
+// rt_flatten.hpp — host side of rt_scene_create: turns the caller's RtSceneDesc
+// (a description of the reference's Scene tree, src/scene.rs:47-53,142-148) into the
+// flat arrays of rt_device_types.h.  Runs once per scene; nothing here is per ray.
+//
+// What replaces what:
+//   * SceneNode::trace's per-level ray transform (scene.rs:198, ray.rs:90-97) and
+//     per-hit `matrix.inverse()` (matrix.rs:55-57) → one composed world<->local pair
+//     and a normal matrix per instance, computed here.
+//   * The median-split kd-tree of src/mesh.rs:281-332 → a binned-SAH binary BVH whose
+//     nodes carry both child boxes (any exact closest-hit structure gives the same
+//     hits; the triangle test itself stays mesh.rs:416-466).
+//   * Box<dyn Shadable> trees → index-linked DShader records plus, per ChainShader, the
+//     flattened list of normal maps its modify_intersect applies (shader.rs:146-152).
+//   * Box<dyn Compositable> trees → a postfix program over leaves with composed transforms.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_device_types.h"
+
+namespace rtflat {
+
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Invalid : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---- 4x4 column-major helpers (m[c*4+r]) ----
+struct Mat4 { double m[16]; };
+inline Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0; return r; }
+inline Mat4 from_pod(const RtMat4& p) { Mat4 r; std::memcpy(r.m, p.m, sizeof r.m); return r; }
+inline Mat4 mul(const Mat4& a, const Mat4& b) {
+    Mat4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int row = 0; row < 4; ++row) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += a.m[k * 4 + row] * b.m[c * 4 + k];
+            r.m[c * 4 + row] = acc;
+        }
+    return r;
+}
+inline Mat4 inverse(const Mat4& a) {   // Gauss-Jordan with partial pivoting
+    double w[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { w[r][c] = a.m[c * 4 + r]; w[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; ++i) {
+        int piv = i;
+        for (int r = i + 1; r < 4; ++r) if (std::fabs(w[r][i]) > std::fabs(w[piv][i])) piv = r;
+        if (w[piv][i] == 0.0) throw Invalid("singular transform");
+        if (piv != i) for (int c = 0; c < 8; ++c) std::swap(w[i][c], w[piv][c]);
+        double d = 1.0 / w[i][i];
+        for (int c = 0; c < 8; ++c) w[i][c] *= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == i) continue;
+            double f = w[r][i];
+            if (f != 0.0) for (int c = 0; c < 8; ++c) w[r][c] -= f * w[i][c];
+        }
+    }
+    Mat4 out;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out.m[c * 4 + r] = w[r][4 + c];
+    return out;
+}
+inline DAffine affine(const Mat4& a) {
+    DAffine r;
+    for (int row = 0; row < 3; ++row) for (int c = 0; c < 4; ++c) r.r[row * 4 + c] = a.m[c * 4 + row];
+    return r;
+}
+inline DXform make_xform(const Mat4& l2w, const Mat4& w2l) {
+    DXform x;
+    x.w2l = affine(w2l);
+    x.l2w = affine(l2w);
+    // n_world ∝ (w2l_lin)^T n_local
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) x.nmat[r * 3 + c] = x.w2l.r[c * 4 + r];
+    // uniform scale?  L^T L = s^2 I
+    double g[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        g[i][j] = 0.0;
+        for (int k = 0; k < 3; ++k) g[i][j] += x.w2l.r[k * 4 + i] * x.w2l.r[k * 4 + j];
+    }
+    double s2 = g[0][0];
+    bool uniform = s2 > 0.0;
+    for (int i = 0; i < 3 && uniform; ++i) for (int j = 0; j < 3; ++j) {
+        double want = i == j ? s2 : 0.0;
+        if (std::fabs(g[i][j] - want) > 1e-12 * s2) { uniform = false; break; }
+    }
+    x.uniform_inv_s = uniform ? 1.0 / std::sqrt(s2) : 0.0;
+    x.uniform_s = uniform ? std::sqrt(s2) : 0.0;
+    return x;
+}
+inline Mat4 rot_x(double deg) { double t = deg * (M_PI / 180.0), s = std::sin(t), c = std::cos(t); return Mat4{{1, 0, 0, 0, 0, c, s, 0, 0, -s, c, 0, 0, 0, 0, 1}}; }
+inline Mat4 rot_y(double deg) { double t = deg * (M_PI / 180.0), s = std::sin(t), c = std::cos(t); return Mat4{{c, 0, -s, 0, 0, 1, 0, 0, s, 0, c, 0, 0, 0, 0, 1}}; }
+inline Mat4 translate(double x, double y, double z) { return Mat4{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, x, y, z, 1}}; }
+inline Mat4 scale(double x, double y, double z) { return Mat4{{x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1}}; }
+
+struct V3 { double x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a * (1.0 / length(a)); }
+inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+// ---- the flattened scene (host copies; uploaded verbatim) ----
+struct FlatScene {
+    std::vector<DInstance> instances;
+    std::vector<DPrim> prims;
+    std::vector<DTri> tris;
+    std::vector<DPoly> polys;
+    std::vector<double> points;
+    std::vector<DFaced> faced;
+    std::vector<DMesh> meshes;
+    std::vector<DBvhNode> bvh_nodes;
+    std::vector<DMeshTri> mesh_tris;
+    std::vector<double> mesh_normals, mesh_uvs;
+    std::vector<DCsgRoot> csg_roots;
+    std::vector<DCsgOp> csg_ops;
+    std::vector<DCsgLeaf> csg_leaves;
+    std::vector<DShader> shaders;
+    std::vector<uint32_t> shader_child_idx;
+    std::vector<double> shader_child_weight;
+    std::vector<uint32_t> chain_nmaps;
+    std::vector<DNormalMap> normal_maps;
+    std::vector<DImage> images;
+    std::vector<uint8_t> texels;
+    std::vector<double> gamma_lut;
+    std::vector<DLight> lights;
+    double ambient[3] = {0, 0, 0};
+    uint32_t has_background = 0, background_image = 0;
+    DAffine background_w2l{};
+    uint32_t max_mesh_bvh_bytes = 0;
+};
+
+// ---- BVH build: binned SAH, leaves of <= 4 triangles ----
+struct BuildTri { V3 lo, hi, c; uint32_t face; };
+struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes, int node_idx, uint32_t first, uint32_t count, int depth) {
+    const double inf = std::numeric_limits<double>::infinity();
+    V3 lo{inf, inf, inf}, hi{-inf, -inf, -inf}, clo = lo, chi = hi;
+    for (uint32_t i = first; i < first + count; ++i) {
+        const BuildTri& t = tris[i];
+        lo = {std::min(lo.x, t.lo.x), std::min(lo.y, t.lo.y), std::min(lo.z, t.lo.z)};
+        hi = {std::max(hi.x, t.hi.x), std::max(hi.y, t.hi.y), std::max(hi.z, t.hi.z)};
+        clo = {std::min(clo.x, t.c.x), std::min(clo.y, t.c.y), std::min(clo.z, t.c.z)};
+        chi = {std::max(chi.x, t.c.x), std::max(chi.y, t.c.y), std::max(chi.z, t.c.z)};
+    }
+    nodes[node_idx].lo = lo; nodes[node_idx].hi = hi;
+    const uint32_t LEAF = 4;
+    if (count <= LEAF || depth >= RT_BVH_STACK - 2) { nodes[node_idx].first = first; nodes[node_idx].count = count; return; }
+    auto area = [](V3 a, V3 b) { V3 d = b - a; return 2.0 * (d.x * d.y + d.y * d.z + d.z * d.x); };
+    const int BINS = 16;
+    double best_cost = inf; int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+        double a0 = axis == 0 ? clo.x : axis == 1 ? clo.y : clo.z, a1 = axis == 0 ? chi.x : axis == 1 ? chi.y : chi.z;
+        if (!(a1 > a0)) continue;
+        struct Bin { V3 lo, hi; uint32_t n = 0; } bins[BINS];
+        for (auto& b : bins) { b.lo = {inf, inf, inf}; b.hi = {-inf, -inf, -inf}; }
+        double k = BINS / (a1 - a0);
+        for (uint32_t i = first; i < first + count; ++i) {
+            const BuildTri& t = tris[i];
+            double c = axis == 0 ? t.c.x : axis == 1 ? t.c.y : t.c.z;
+            int b = std::min(BINS - 1, (int)((c - a0) * k));
+            bins[b].n++;
+            bins[b].lo = {std::min(bins[b].lo.x, t.lo.x), std::min(bins[b].lo.y, t.lo.y), std::min(bins[b].lo.z, t.lo.z)};
+            bins[b].hi = {std::max(bins[b].hi.x, t.hi.x), std::max(bins[b].hi.y, t.hi.y), std::max(bins[b].hi.z, t.hi.z)};
+        }
+        double right_area[BINS]; uint32_t right_n[BINS];
+        V3 rl{inf, inf, inf}, rh{-inf, -inf, -inf}; uint32_t rn = 0;
+        for (int b = BINS - 1; b > 0; --b) {
+            rn += bins[b].n;
+            rl = {std::min(rl.x, bins[b].lo.x), std::min(rl.y, bins[b].lo.y), std::min(rl.z, bins[b].lo.z)};
+            rh = {std::max(rh.x, bins[b].hi.x), std::max(rh.y, bins[b].hi.y), std::max(rh.z, bins[b].hi.z)};
+            right_area[b] = rn ? area(rl, rh) : 0.0; right_n[b] = rn;
+        }
+        V3 ll{inf, inf, inf}, lh{-inf, -inf, -inf}; uint32_t ln = 0;
+        for (int b = 0; b < BINS - 1; ++b) {
+            ln += bins[b].n;
+            ll = {std::min(ll.x, bins[b].lo.x), std::min(ll.y, bins[b].lo.y), std::min(ll.z, bins[b].lo.z)};
+            lh = {std::max(lh.x, bins[b].hi.x), std::max(lh.y, bins[b].hi.y), std::max(lh.z, bins[b].hi.z)};
+            if (ln == 0 || right_n[b + 1] == 0) continue;
+            double cost = ln * area(ll, lh) + right_n[b + 1] * right_area[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+    }
+    uint32_t mid;
+    if (best_axis < 0) {   // all centroids coincide: split in the middle
+        mid = first + count / 2;
+    } else {
+        double a0 = best_axis == 0 ? clo.x : best_axis == 1 ? clo.y : clo.z, a1 = best_axis == 0 ? chi.x : best_axis == 1 ? chi.y : chi.z;
+        double k = BINS / (a1 - a0);
+        auto it = std::partition(tris.begin() + first, tris.begin() + first + count, [&](const BuildTri& t) {
+            double c = best_axis == 0 ? t.c.x : best_axis == 1 ? t.c.y : t.c.z;
+            return std::min(BINS - 1, (int)((c - a0) * k)) <= best_bin;
+        });
+        mid = (uint32_t)(it - tris.begin());
+        if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    int l = (int)nodes.size(); nodes.emplace_back();
+    int r = (int)nodes.size(); nodes.emplace_back();
+    nodes[node_idx].left = l; nodes[node_idx].right = r;
+    build_bvh(tris, nodes, l, first, mid - first, depth + 1);
+    build_bvh(tris, nodes, r, mid, first + count - mid, depth + 1);
+}
+
+inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& m) {
+    if (m.num_faces == 0) throw Invalid("mesh without faces");
+    const double* P = d.mesh_f64 + m.positions_off;
+    const uint32_t* F = d.mesh_u32 + m.faces_off;
+    auto pos = [&](uint32_t i) { if (i >= m.num_positions) throw Invalid("mesh face index out of range"); return V3{P[3 * i], P[3 * i + 1], P[3 * i + 2]}; };
+    std::vector<BuildTri> bt(m.num_faces);
+    for (uint32_t f = 0; f < m.num_faces; ++f) {
+        V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
+        bt[f].lo = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
+        bt[f].hi = {std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z))};
+        bt[f].c = (bt[f].lo + bt[f].hi) * 0.5;
+        bt[f].face = f;
+    }
+    std::vector<BuildNode> bn(1);
+    bn.reserve(2 * m.num_faces + 2);
+    build_bvh(bt, bn, 0, 0, m.num_faces, 0);
+    // pad boxes so that slab-test rounding can never cull a triangle lying on a box face
+    V3 ext = bn[0].hi - bn[0].lo;
+    double pad = 1e-9 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-300;
+    DMesh dm{};
+    dm.node_off = (uint32_t)fs.bvh_nodes.size();
+    dm.tri_off = (uint32_t)fs.mesh_tris.size();
+    dm.num_tris = m.num_faces;
+    put(dm.lo, bn[0].lo - V3{pad, pad, pad}); put(dm.hi, bn[0].hi + V3{pad, pad, pad});
+    // triangles in BVH order; derived values as Mesh::from_path computes them (mesh.rs:396-404)
+    for (uint32_t i = 0; i < m.num_faces; ++i) {
+        uint32_t f = bt[i].face;
+        V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
+        V3 cr = cross(b - a, c - b);
+        DMeshTri t{};
+        put(t.v1, a); put(t.v2, b); put(t.v3, c); put(t.n, normalize(cr));
+        t.inv_area = 1.0 / length(cr);
+        t.i1 = F[3 * f]; t.i2 = F[3 * f + 1]; t.i3 = F[3 * f + 2]; t.face = f;
+        fs.mesh_tris.push_back(t);
+    }
+    // interior nodes only; node 0 = root.  A single-leaf mesh gets a root whose second child is empty.
+    std::vector<int> interior_index(bn.size(), -1);
+    std::vector<int> order;
+    for (size_t i = 0; i < bn.size(); ++i) if (bn[i].left >= 0) { interior_index[i] = (int)order.size(); order.push_back((int)i); }
+    auto child_ref = [&](int b, uint32_t& ref, uint32_t& cnt) {
+        if (bn[b].left >= 0) { ref = (uint32_t)interior_index[b]; cnt = 0; }
+        else { ref = 0x80000000u | bn[b].first; cnt = bn[b].count; }
+    };
+    auto set_box = [&](DBvhNode& n, int k, const BuildNode& b) {
+        n.lo[k][0] = b.lo.x - pad; n.lo[k][1] = b.lo.y - pad; n.lo[k][2] = b.lo.z - pad;
+        n.hi[k][0] = b.hi.x + pad; n.hi[k][1] = b.hi.y + pad; n.hi[k][2] = b.hi.z + pad;
+    };
+    if (order.empty()) {
+        DBvhNode n{};
+        set_box(n, 0, bn[0]);
+        n.child[0] = 0x80000000u | bn[0].first; n.count[0] = bn[0].count;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (int k = 0; k < 3; ++k) { n.lo[1][k] = inf; n.hi[1][k] = -inf; }
+        n.child[1] = 0x80000000u; n.count[1] = 0;
+        fs.bvh_nodes.push_back(n);
+    } else {
+        for (int b : order) {
+            DBvhNode n{};
+            set_box(n, 0, bn[bn[b].left]); set_box(n, 1, bn[bn[b].right]);
+            child_ref(bn[b].left, n.child[0], n.count[0]);
+            child_ref(bn[b].right, n.child[1], n.count[1]);
+            fs.bvh_nodes.push_back(n);
+        }
+    }
+    dm.num_nodes = (uint32_t)fs.bvh_nodes.size() - dm.node_off;
+    dm.normal_off = (uint32_t)(fs.mesh_normals.size() / 3);
+    dm.num_normals = m.num_normals;
+    fs.mesh_normals.insert(fs.mesh_normals.end(), d.mesh_f64 + m.normals_off, d.mesh_f64 + m.normals_off + 3 * (size_t)m.num_normals);
+    dm.uv_off = (uint32_t)(fs.mesh_uvs.size() / 2);
+    dm.num_uvs = m.num_texcoords;
+    fs.mesh_uvs.insert(fs.mesh_uvs.end(), d.mesh_f64 + m.texcoords_off, d.mesh_f64 + m.texcoords_off + 2 * (size_t)m.num_texcoords);
+    fs.meshes.push_back(dm);
+    uint32_t bytes = dm.num_nodes * (uint32_t)sizeof(DBvhNode) + dm.num_tris * (uint32_t)sizeof(DMeshTri);
+    fs.max_mesh_bvh_bytes = std::max(fs.max_mesh_bvh_bytes, bytes);
+    return (uint32_t)fs.meshes.size() - 1;
+}
+
+inline DTri make_tri(V3 v1, V3 v2, V3 v3) {   // Triangle::from_vertices, plane.rs:111-126
+    DTri t{};
+    V3 e0 = v2 - v1, e1 = v3 - v2, e2 = v1 - v3;
+    put(t.v, v1); put(t.v + 3, v2); put(t.v + 6, v3);
+    put(t.e, e0); put(t.e + 3, e1); put(t.e + 6, e2);
+    V3 a_side = e2 * -1.0, b_side = e0;
+    V3 h = a_side - b_side * (dot(a_side, b_side) / dot(b_side, b_side));
+    put(t.tangent, normalize(h));
+    V3 w = a_side - h;
+    t.sc_height = length(h);
+    t.sc_width = std::max(length(w), length(b_side));
+    put(t.n, normalize(cross(e0, e1)));
+    t.side_c = length(e0);
+    return t;
+}
+
+class Flattener {
+public:
+    Flattener(const RtSceneDesc& d, FlatScene& fs) : d_(d), fs_(fs), prim_map_(d.num_prims, RT_NONE), mesh_map_(d.num_meshes, RT_NONE) {}
+
+    void run() {
+        if (d_.abi_version != RT_ABI_VERSION) throw Invalid("RtSceneDesc.abi_version mismatch");
+        if (d_.num_nodes == 0 || !d_.nodes) throw Invalid("scene has no nodes");
+        images();
+        shaders();
+        // lights
+        for (uint32_t i = 0; i < d_.num_lights; ++i) {
+            const RtLight& l = d_.lights[i];
+            if (l.kind > RT_LIGHT_DIRECTION) throw Invalid("unknown light kind");
+            DLight o{};
+            o.kind = l.kind; o.index = i;
+            std::memcpy(o.position, l.position, sizeof o.position);
+            std::memcpy(o.color, l.color, sizeof o.color);
+            std::memcpy(o.falloff, l.falloff, sizeof o.falloff);
+            o.power = l.power; o.size = l.size; o.inv_area = l.size != 0.0 ? 1.0 / (l.size * l.size) : 0.0;
+            fs_.lights.push_back(o);
+        }
+        for (int k = 0; k < 3; ++k) fs_.ambient[k] = d_.ambient_color[k] * d_.ambient_power;   // light.rs:77-79
+        if (d_.has_background) {
+            if (d_.background_image >= d_.num_images) throw Invalid("background image out of range");
+            fs_.has_background = 1; fs_.background_image = d_.background_image;
+            fs_.background_w2l = affine(inverse(from_pod(d_.background_trans)));
+        }
+        // instances: DFS pre-order with composed transforms
+        walk(0, identity(), identity());
+    }
+
+private:
+    const RtSceneDesc& d_;
+    FlatScene& fs_;
+    std::vector<uint32_t> prim_map_, mesh_map_;
+
+    void walk(uint32_t i, const Mat4& parent_l2w, const Mat4& parent_w2l) {
+        if (i >= d_.num_nodes) throw Invalid("node index out of range");
+        const RtNode& n = d_.nodes[i];
+        Mat4 t = from_pod(n.trans);
+        Mat4 l2w = mul(parent_l2w, t);
+        Mat4 w2l = mul(inverse(t), parent_w2l);
+        if (n.prim != RT_NONE) {
+            DInstance inst{};
+            inst.x = make_xform(l2w, w2l);
+            inst.prim = prim(n.prim);
+            if (n.shader >= d_.num_shaders) throw Invalid("node shader out of range");
+            inst.shader = n.shader;
+            inst.node_id = i;
+            inst.is_root = i == 0;
+            fs_.instances.push_back(inst);
+        }
+        if (n.subtree_size == 0 || i + n.subtree_size > d_.num_nodes) throw Invalid("bad subtree_size");
+        for (uint32_t c = i + 1; c < i + n.subtree_size; c += d_.nodes[c].subtree_size) walk(c, l2w, w2l);
+    }
+
+    uint32_t prim(uint32_t i) {
+        if (i >= d_.num_prims) throw Invalid("primitive index out of range");
+        if (prim_map_[i] != RT_NONE) return prim_map_[i];
+        const RtPrim& p = d_.prims[i];
+        DPrim o{};
+        switch (p.kind) {
+            case RT_PRIM_SPHERE: o.kind = DP_SPHERE; o.p[0] = p.p[0]; break;
+            case RT_PRIM_RECTANGLE: o.kind = DP_RECTANGLE; o.p[0] = p.p[0]; o.p[1] = p.p[1]; break;
+            case RT_PRIM_PLANE: o.kind = DP_PLANE; std::memcpy(o.p, p.p, sizeof o.p); break;
+            case RT_PRIM_TRIANGLE:
+                o.kind = DP_TRIANGLE; o.ref = (uint32_t)fs_.tris.size();
+                fs_.tris.push_back(make_tri({p.p[0], p.p[1], p.p[2]}, {p.p[3], p.p[4], p.p[5]}, {p.p[6], p.p[7], p.p[8]}));
+                break;
+            case RT_PRIM_POLYGON: {   // Polygon::from_vertices, plane.rs:181-202
+                if (p.count < 3 || (uint64_t)p.ref + p.count > d_.num_points) throw Invalid("polygon vertices out of range");
+                std::vector<V3> v(p.count);
+                for (uint32_t k = 0; k < p.count; ++k) v[k] = {d_.points[(p.ref + k) * 3], d_.points[(p.ref + k) * 3 + 1], d_.points[(p.ref + k) * 3 + 2]};
+                std::vector<V3> e;
+                e.push_back(v[0] - v[p.count - 1]);
+                e.push_back(v[1] - v[0]);
+                V3 n = normalize(cross(e[0], e[1]));
+                for (uint32_t k = 2; k + 1 < p.count; ++k) v[k] = v[k] - n * dot(v[k] - v[0], n);
+                for (uint32_t k = 2; k < p.count; ++k) e.push_back(v[k] - v[(k - 1) % p.count]);
+                DPoly poly{};
+                poly.count = p.count; put(poly.n, n);
+                poly.first_vertex = (uint32_t)(fs_.points.size() / 3);
+                for (auto& q : v) { fs_.points.push_back(q.x); fs_.points.push_back(q.y); fs_.points.push_back(q.z); }
+                poly.first_edge = (uint32_t)(fs_.points.size() / 3);
+                for (auto& q : e) { fs_.points.push_back(q.x); fs_.points.push_back(q.y); fs_.points.push_back(q.z); }
+                o.kind = DP_POLYGON; o.ref = (uint32_t)fs_.polys.size();
+                fs_.polys.push_back(poly);
+                break;
+            }
+            case RT_PRIM_CUBE: {      // Cube::new, cube.rs:14-31
+                double length = p.p[0];
+                DFaced f{};
+                f.nfaces = 6; f.base_is_triangle = 0; f.is_cube = 1; f.base_w = length; f.base_h = length;
+                Mat4 t = translate(0.0, 0.0, length / 2.0);
+                Mat4 m[6] = {mul(rot_y(90.0), t), mul(rot_y(-90.0), t), t, mul(rot_y(180.0), t), mul(rot_x(-90.0), t), mul(rot_x(90.0), t)};
+                for (int k = 0; k < 6; ++k) f.face[k] = make_xform(m[k], inverse(m[k]));
+                o.kind = DP_FACED; o.ref = (uint32_t)fs_.faced.size();
+                fs_.faced.push_back(f);
+                break;
+            }
+            case RT_PRIM_TETRAHEDRON: {   // Tetrahedron::new, cube.rs:103-122
+                double size = p.p[0];
+                double tri_height = size * std::sin(M_PI / 3.0);
+                DFaced f{};
+                f.nfaces = 4; f.base_is_triangle = 1; f.is_cube = 0;
+                f.base_tri = (uint32_t)fs_.tris.size();
+                fs_.tris.push_back(make_tri({-size / 2.0, 0.0, 0.0}, {size / 2.0, 0.0, 0.0}, {0.0, 0.0, -tri_height}));
+                Mat4 t = translate(0.0, 0.0, tri_height / 3.0);
+                Mat4 m1 = mul(t, rot_x(std::acos(1.0 / 3.0) * (180.0 / M_PI)));
+                Mat4 m[4] = {mul(scale(1.0, -1.0, 1.0), t), m1, mul(rot_y(-120.0), m1), mul(rot_y(120.0), m1)};
+                for (int k = 0; k < 4; ++k) f.face[k] = make_xform(m[k], inverse(m[k]));
+                o.kind = DP_FACED; o.ref = (uint32_t)fs_.faced.size();
+                fs_.faced.push_back(f);
+                break;
+            }
+            case RT_PRIM_POLYHEDRON: {
+                if (p.count == 0 || p.count > 32 || (uint64_t)p.ref + p.count > d_.num_prims) throw Invalid("polyhedron planes out of range");
+                // planes must be contiguous in the device array: emit them now
+                uint32_t first = (uint32_t)fs_.prims.size();
+                for (uint32_t k = 0; k < p.count; ++k) {
+                    const RtPrim& pl = d_.prims[p.ref + k];
+                    if (pl.kind != RT_PRIM_PLANE) throw Invalid("polyhedron entry is not a plane");
+                    DPrim q{}; q.kind = DP_PLANE; std::memcpy(q.p, pl.p, sizeof q.p);
+                    fs_.prims.push_back(q);
+                }
+                o.kind = DP_POLYHEDRON; o.ref = first; o.count = p.count;
+                break;
+            }
+            case RT_PRIM_ONEWAY:
+            case RT_PRIM_INVERTED: {
+                uint32_t inner = prim(p.ref);
+                o = fs_.prims[inner];
+                uint32_t levels = 0;
+                while (levels < 16 && ((o.wrap >> (2 * levels)) & 3u)) ++levels;
+                if (levels >= 8) throw Unsupported("more than 8 nested OneWay/Inverted wrappers");
+                if (o.kind == DP_CSG) throw Unsupported("OneWay/Inverted around a composite shape");
+                o.wrap |= (p.kind == RT_PRIM_ONEWAY ? DWRAP_ONEWAY : DWRAP_INVERTED) << (2 * levels);
+                break;
+            }
+            case RT_PRIM_MESH:
+                if (p.ref >= d_.num_meshes) throw Invalid("mesh index out of range");
+                if (mesh_map_[p.ref] == RT_NONE) mesh_map_[p.ref] = flatten_mesh(fs_, d_, d_.meshes[p.ref]);
+                o.kind = DP_MESH; o.ref = mesh_map_[p.ref];
+                break;
+            case RT_PRIM_CSG: {
+                if (p.ref >= d_.num_csg) throw Invalid("csg index out of range");
+                DCsgRoot root{};
+                root.op_begin = (uint32_t)fs_.csg_ops.size();
+                uint32_t lists = 0;
+                csg(p.ref, identity(), identity(), 0, lists);
+                root.op_count = (uint32_t)fs_.csg_ops.size() - root.op_begin;
+                o.kind = DP_CSG; o.ref = (uint32_t)fs_.csg_roots.size();
+                fs_.csg_roots.push_back(root);
+                break;
+            }
+            default: throw Invalid("unknown primitive kind");
+        }
+        uint32_t idx = (uint32_t)fs_.prims.size();
+        fs_.prims.push_back(o);
+        prim_map_[i] = idx;
+        return idx;
+    }
+
+    // Post-order emission; every transform above a leaf is folded into the leaf.
+    void csg(uint32_t i, const Mat4& parent_l2w, const Mat4& parent_w2l, int depth, uint32_t& live_lists) {
+        if (i >= d_.num_csg) throw Invalid("csg index out of range");
+        if (depth > 16) throw Unsupported("composite shape nested deeper than 16");
+        const RtCsgNode& n = d_.csg[i];
+        Mat4 t = from_pod(n.trans);
+        Mat4 l2w = mul(parent_l2w, t), w2l = mul(inverse(t), parent_w2l);
+        DCsgOp op{};
+        if (n.kind == RT_CSG_BASE) {
+            DCsgLeaf leaf{};
+            leaf.x = make_xform(l2w, w2l);
+            leaf.prim = prim(n.prim);
+            if (fs_.prims[leaf.prim].kind == DP_CSG) throw Unsupported("BaseShape wrapping a composite shape");
+            op.kind = DC_BASE; op.leaf = (uint32_t)fs_.csg_leaves.size();
+            fs_.csg_leaves.push_back(leaf);
+            if (++live_lists > RT_CSG_MAX_LISTS) throw Unsupported("composite shape needs too many simultaneous hit lists");
+        } else {
+            if (n.kind > RT_CSG_MULTI_AND) throw Invalid("unknown csg kind");
+            if (n.kind != RT_CSG_MULTI_AND && n.num_children != 2) throw Invalid("binary composite needs two children");
+            if (n.num_children == 0 || n.num_children > 8) throw Unsupported("composite with more than 8 children");
+            for (uint32_t k = 0; k < n.num_children; ++k) csg(d_.csg_children[n.first_child + k], l2w, w2l, depth + 1, live_lists);
+            op.kind = n.kind;   // RT_CSG_* and DC_* share values
+            op.num_children = n.num_children;
+            live_lists -= n.num_children - 1;
+        }
+        fs_.csg_ops.push_back(op);
+    }
+
+    void images() {
+        fs_.gamma_lut.resize(256);
+        for (int i = 0; i < 256; ++i) fs_.gamma_lut[i] = std::pow((double)i / 255.0, 2.2);   // color.rs:78-84
+        for (uint32_t i = 0; i < d_.num_images; ++i) {
+            const RtImage& s = d_.images[i];
+            if (s.width < 2 || s.height < 2 || (s.channels != 1 && s.channels != 3)) throw Invalid("image must be at least 2x2 with 1 or 3 channels");
+            size_t row = (size_t)s.width * s.channels;
+            if (s.offset + row * s.height > d_.texel_bytes) throw Invalid("image texels out of range");
+            DImage o{};
+            o.width = s.width; o.height = s.height; o.channels = s.channels;
+            while (fs_.texels.size() % 16) fs_.texels.push_back(0);
+            o.offset = fs_.texels.size();
+            fs_.texels.resize(o.offset + row * s.height);
+            for (uint32_t y = 0; y < s.height; ++y)   // flip_vertical: texture.rs:46, normal_map.rs:52,116
+                std::memcpy(&fs_.texels[o.offset + (size_t)y * row], d_.texels + s.offset + (size_t)(s.height - 1 - y) * row, row);
+            fs_.images.push_back(o);
+        }
+        for (uint32_t i = 0; i < d_.num_normal_maps; ++i) {
+            const RtNormalMap& s = d_.normal_maps[i];
+            if (s.image >= d_.num_images) throw Invalid("normal map image out of range");
+            if ((s.kind == RT_NMAP_NORMAL && d_.images[s.image].channels != 3) || (s.kind == RT_NMAP_BUMP && d_.images[s.image].channels != 1))
+                throw Invalid("normal map image has the wrong channel count");
+            fs_.normal_maps.push_back(DNormalMap{s.kind, s.image, s.depth});
+        }
+    }
+
+    void collect_chain_nmaps(uint32_t i, int depth) {   // ChainShader::modify_intersect, shader.rs:146-152
+        if (depth > 16) throw Unsupported("shader chain nested deeper than 16");
+        const RtShader& s = d_.shaders[i];
+        if (s.kind == RT_SHADER_NORMAL_MAP) fs_.chain_nmaps.push_back(s.ref);
+        else if (s.kind == RT_SHADER_CHAIN)
+            for (uint32_t k = 0; k < s.num_children; ++k) collect_chain_nmaps(d_.shader_child_idx[s.first_child + k], depth + 1);
+    }
+    // true if evaluating the shader can spawn secondary rays
+    bool spawns(uint32_t i, int depth) {
+        if (depth > RT_SHADE_MAX_FRAMES) throw Unsupported("shader tree nested deeper than the interpreter's frame stack");
+        const RtShader& s = d_.shaders[i];
+        switch (s.kind) {
+            case RT_SHADER_REFLECTION: case RT_SHADER_TRANSLUCENT: return true;
+            case RT_SHADER_MIX: {
+                int n = 0;
+                for (uint32_t k = 0; k < s.num_children; ++k) n += spawns(d_.shader_child_idx[s.first_child + k], depth + 1);
+                if (n > 1) throw Unsupported("MixShader with more than one ray-spawning factor (product of two ray colours)");
+                return n > 0;
+            }
+            case RT_SHADER_COMPOSITE: {
+                bool any = false;
+                for (uint32_t k = 0; k < s.num_children; ++k) any |= spawns(d_.shader_child_idx[s.first_child + k], depth + 1);
+                return any;
+            }
+            case RT_SHADER_CHAIN:
+                if (s.num_children == 0) throw Invalid("Chain Shader needs at least one shader to function");
+                return spawns(d_.shader_child_idx[s.first_child + s.num_children - 1], depth + 1);
+            default: return false;
+        }
+    }
+    uint32_t count_spawns(uint32_t i) {
+        const RtShader& s = d_.shaders[i];
+        switch (s.kind) {
+            case RT_SHADER_REFLECTION: return 1;
+            case RT_SHADER_TRANSLUCENT: return 2;
+            case RT_SHADER_MIX: case RT_SHADER_COMPOSITE: {
+                uint32_t n = 0;
+                for (uint32_t k = 0; k < s.num_children; ++k) n += count_spawns(d_.shader_child_idx[s.first_child + k]);
+                return n;
+            }
+            case RT_SHADER_CHAIN: return count_spawns(d_.shader_child_idx[s.first_child + s.num_children - 1]);
+            default: return 0;
+        }
+    }
+    void shaders() {
+        for (uint32_t i = 0; i < d_.num_shaders; ++i) {
+            const RtShader& s = d_.shaders[i];
+            if (s.kind > RT_SHADER_NORMAL_MAP) throw Invalid("unknown shader kind");
+            if ((uint64_t)s.first_child + s.num_children > d_.num_shader_children) throw Invalid("shader children out of range");
+            for (uint32_t k = 0; k < s.num_children; ++k)
+                if (d_.shader_child_idx[s.first_child + k] >= d_.num_shaders) throw Invalid("shader child out of range");
+            if (s.kind == RT_SHADER_TEXTURE && (s.ref >= d_.num_images || d_.images[s.ref].channels != 3)) throw Invalid("texture shader image invalid");
+            if (s.kind == RT_SHADER_NORMAL_MAP && s.ref >= d_.num_normal_maps) throw Invalid("normal map index out of range");
+        }
+        for (uint32_t i = 0; i < d_.num_shaders; ++i) {
+            const RtShader& s = d_.shaders[i];
+            DShader o{};
+            o.kind = s.kind; o.ref = s.ref; o.first_child = s.first_child; o.num_children = s.num_children;
+            std::memcpy(o.p, s.p, sizeof o.p);
+            if (s.kind == RT_SHADER_CHAIN) {
+                o.nm_begin = (uint32_t)fs_.chain_nmaps.size();
+                collect_chain_nmaps(i, 0);
+                o.nm_count = (uint32_t)fs_.chain_nmaps.size() - o.nm_begin;
+            }
+            spawns(i, 0);
+            if (count_spawns(i) > RT_SHADE_MAX_SPAWN) throw Unsupported("shader spawns more secondary rays per hit than the device path buffers");
+            fs_.shaders.push_back(o);
+        }
+        fs_.shader_child_idx.assign(d_.shader_child_idx, d_.shader_child_idx + d_.num_shader_children);
+        fs_.shader_child_weight.assign(d_.shader_child_weight, d_.shader_child_weight + d_.num_shader_children);
+    }
+};
+
+inline void flatten(const RtSceneDesc& d, FlatScene& fs) { Flattener(d, fs).run(); }
+
+}  // namespace rtflat

@@ -1,0 +1,73 @@
+// rt_math.h — f64 vector helpers and the counter-based RNG for the device path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device_types.h"
+
+#define RT_DEV __device__ __forceinline__
+
+struct d3 {
+    double x, y, z;
+};
+RT_DEV d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV d3 ld3(const double* p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV d3 operator*(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV d3 operator*(double s, d3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV d3 operator*(d3 a, d3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }   // colours
+RT_DEV d3 operator/(d3 a, double s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV d3 cross(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV double length(d3 a) { return sqrt(dot(a, a)); }
+RT_DEV d3 normalize(d3 a) { return a * (1.0 / length(a)); }   // cgmath: v * (1/|v|)
+RT_DEV d3 neg(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+
+RT_DEV d3 xf_point(const DAffine& m, d3 p) {
+    return mk3(((m.r[0] * p.x + m.r[1] * p.y) + m.r[2] * p.z) + m.r[3],
+               ((m.r[4] * p.x + m.r[5] * p.y) + m.r[6] * p.z) + m.r[7],
+               ((m.r[8] * p.x + m.r[9] * p.y) + m.r[10] * p.z) + m.r[11]);
+}
+RT_DEV d3 xf_vector(const DAffine& m, d3 v) {
+    return mk3((m.r[0] * v.x + m.r[1] * v.y) + m.r[2] * v.z,
+               (m.r[4] * v.x + m.r[5] * v.y) + m.r[6] * v.z,
+               (m.r[8] * v.x + m.r[9] * v.y) + m.r[10] * v.z);
+}
+RT_DEV d3 xf_normal(const double* n9, d3 n) {
+    return normalize(mk3((n9[0] * n.x + n9[1] * n.y) + n9[2] * n.z,
+                         (n9[3] * n.x + n9[4] * n.y) + n9[5] * n.z,
+                         (n9[6] * n.x + n9[7] * n.y) + n9[8] * n.z));
+}
+
+RT_DEV double fract_(double x) { return x - trunc(x); }   // Rust f64::fract
+
+// SurfaceCoord::new (src/geometry/surface_coord.rs:9-19)
+RT_DEV void surface_coord(double u, double v, double& ou, double& ov) {
+    u = fract_(u); v = fract_(v);
+    ou = u < 0.0 ? 1.0 + u : u;
+    ov = v < 0.0 ? 1.0 + v : v;
+}
+
+// ---- counter-based RNG: the specification both the device path and the CPU checker follow ----
+RT_DEV uint64_t sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RT_DEV double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+RT_DEV uint64_t rng_stream(uint64_t seed, uint64_t pixel, uint32_t sample) {
+    uint64_t h = sm64(seed);
+    h = sm64(h ^ pixel);
+    return sm64(h ^ (uint64_t)sample);
+}
+RT_DEV uint32_t hash32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+RT_DEV uint32_t child_path(uint32_t parent, uint32_t ordinal) { return hash32(parent ^ hash32(ordinal + 0x9E3779B9u)); }
+RT_DEV double rng_light(uint64_t stream, uint32_t path, uint32_t light, uint32_t counter) {
+    return u01(sm64(stream ^ (((uint64_t)path << 32) | ((uint64_t)(light & 0x3FFu) << 22) | (uint64_t)(counter & 0x3FFFFFu))));
+}
+RT_DEV double rng_aa(uint64_t stream0, uint32_t index) { return u01(sm64(stream0 ^ (0xA5A5A5A500000000ull + index))); }

@@ -1,0 +1,331 @@
+// rt_shade.h — device-side shading: textures, normal/bump maps, lights (point, square
+// area light with adaptive subdivision, directional), Phong, and the interpreter that
+// walks a material's shader tree at a hit.
+//
+// The reference evaluates Shadable::get_color recursively and lets reflective /
+// translucent shaders call Scene::cast_ray from inside the recursion
+// (src/shader/*.rs).  Here a hit is shaded in one pass that returns
+//      colour(hit) = L + Σ_k W_k ∘ colour(ray_k)
+// i.e. a local colour L plus a short list of secondary rays with per-channel weights
+// W_k and cut-off contributions C_k.  The caller adds weight∘L to the pixel and pushes
+// the rays on its stack; no recursion is needed because every group shader is linear
+// in the colours of the rays below it (MixShader with two ray-spawning factors is the
+// one non-linear case and is refused when the scene is created).
+#pragma once
+#include "rt_trace.h"
+
+struct Spawn {            // a secondary ray requested by the shader tree
+    d3 o, d;
+    d3 w;                 // multiplies the ray's colour in this hit's colour
+    d3 c;                 // Ray::contribution of the new ray (ray.rs:22-26)
+    uint32_t ordinal;     // identifies the spawning shader + branch for the RNG path
+};
+
+// ------------------------------------------------------------------ images
+RT_DEV d3 texel_rgb(const DScene& sc, const DImage& im, uint32_t x, uint32_t y) {   // Color::from_rgb, color.rs:78-84
+    const uint8_t* p = sc.texels + im.offset + ((size_t)y * im.width + x) * 3;
+    return mk3(sc.gamma_lut[p[0]], sc.gamma_lut[p[1]], sc.gamma_lut[p[2]]);
+}
+// ImageTexture::get_color (src/texture.rs:52-69), including the (w-1)x(h-1) grid and the
+// swapped vertical weights.
+RT_DEV d3 texture_color(const DScene& sc, uint32_t image, double u, double v) {
+    const DImage& im = sc.images[image];
+    double gu = fract_(u) * (double)(im.width - 1), gv = fract_(v) * (double)(im.height - 1);
+    uint32_t x = (uint32_t)floor(gu), y = (uint32_t)floor(gv);
+    double fu = fract_(gu), fv = fract_(gv);
+    d3 up_left = texel_rgb(sc, im, x, y), up_right = texel_rgb(sc, im, x + 1, y);
+    d3 bot_left = texel_rgb(sc, im, x, y + 1), bot_right = texel_rgb(sc, im, x + 1, y + 1);
+    return ((up_left * (1.0 - fu) * fv + up_right * fu * fv) + bot_left * (1.0 - fu) * (1.0 - fv)) + bot_right * fu * (1.0 - fv);
+}
+// Scene::get_background_color / SkyBox::get_color (src/scene.rs:99-106, 31-43)
+RT_DEV d3 background_color(const DScene& sc, d3 dir) {
+    if (!sc.has_background) return mk3(0.0, 0.0, 0.0);
+    d3 d = normalize(xf_vector(sc.background_w2l, dir));
+    double azimuth = atan2(d.z, d.x);
+    double elevation = asin(d.y);
+    double u, v;
+    surface_coord((azimuth / 2.0) / RT_PI + 0.5, elevation / RT_PI + 0.5, u, v);
+    return texture_color(sc, sc.background_image, u, v);
+}
+
+// ------------------------------------------------------------------ normal maps (src/normal_map.rs)
+RT_DEV double bump_height(const DScene& sc, const DImage& im, double depth, uint32_t x, uint32_t y) {   // :57-60
+    return ((double)sc.texels[im.offset + (size_t)y * im.width + x] / 255.0) * depth;
+}
+RT_DEV d3 map_normal(const DScene& sc, const DNormalMap& nm, double u, double v) {
+    const DImage& im = sc.images[nm.image];
+    if (nm.kind == 0) {                                           // NormalMap::get_normal :122-129
+        uint32_t x = (uint32_t)floor(fract_(u) * (double)im.width), y = (uint32_t)floor(fract_(v) * (double)im.height);
+        const uint8_t* p = sc.texels + im.offset + ((size_t)y * im.width + x) * 3;
+        return normalize(mk3((double)(128 - (int)p[0]), (double)(128 - (int)p[1]), (double)p[2]));
+    }
+    double gu = fract_(u) * (double)(im.width - 1), gv = fract_(v) * (double)(im.height - 1);   // BumpMap::get_normal :64-96
+    uint32_t x = (uint32_t)floor(gu), y = (uint32_t)floor(gv);
+    double fu = fract_(gu), fv = fract_(gv);
+    double up_left = bump_height(sc, im, nm.depth, x, y), up_right = bump_height(sc, im, nm.depth, x + 1, y);
+    double bot_left = bump_height(sc, im, nm.depth, x, y + 1), bot_right = bump_height(sc, im, nm.depth, x + 1, y + 1);
+    double up = fu * up_right + (1.0 - fu) * up_left;
+    double bot = fu * bot_right + (1.0 - fu) * bot_left;
+    double h = up - bot;
+    double h_denom = sqrt(h * h + 1.0);
+    d3 y_vec = mk3(0.0, h / h_denom, 1.0 / h_denom);
+    double left = fv * up_left + (1.0 - fv) * bot_left;
+    double right = fv * up_right + (1.0 - fv) * bot_right;
+    h = right - left;
+    h_denom = sqrt(h * h + 1.0);
+    d3 x_vec = mk3(h / h_denom, 0.0, 1.0 / h_denom);
+    return normalize(y_vec + x_vec);
+}
+// NormalMappable::calculate_normal = basis(old_normal, tangent) * n  (normal_map.rs:10-12, matrix.rs:112-128)
+RT_DEV d3 perturbed_normal(const DScene& sc, const DNormalMap& nm, double u, double v, d3 old_normal, d3 up) {
+    d3 n = map_normal(sc, nm, u, v);
+    if (up.x == old_normal.x && up.y == old_normal.y && up.z == old_normal.z) up = mk3(0.0, 0.0, -1.0);
+    d3 side = normalize(cross(old_normal, up));
+    d3 up2 = normalize(cross(side, old_normal));
+    return mk3((side.x * n.x + up2.x * n.y) + old_normal.x * n.z,
+               (side.y * n.x + up2.y * n.y) + old_normal.y * n.z,
+               (side.z * n.x + up2.z * n.y) + old_normal.z * n.z);
+}
+
+// ------------------------------------------------------------------ Phong + lights
+struct PhongCtx {
+    d3 p, n, view;        // hit point, (possibly perturbed) normal, -ray.direction
+    d3 diffuse, specular;
+    double shininess;
+    d3 total;
+};
+// one Illum::Lit term of PhongShader::get_color (src/shader/phong.rs:37-42)
+RT_DEV void phong_lit(PhongCtx& c, double surface_dot, d3 light_direction, d3 intensity) {
+    d3 reflection_direction = normalize(2.0 * surface_dot * c.n - light_direction);
+    double specular_factor = pow(fmax(dot(reflection_direction, c.view), 0.0), c.shininess) / surface_dot;
+    d3 phong_color = c.specular * specular_factor + c.diffuse;
+    c.total = c.total + phong_color * surface_dot * intensity;
+}
+
+// SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
+// an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
+// order so that the draw counter of the RNG advances identically.
+template <bool COUNT>
+RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
+    struct Quad { double minx, miny, maxx, maxy; uint32_t depth; };
+    Quad st[16];
+    int sp = 0;
+    double half = L.size * 0.5;
+    st[sp++] = Quad{-half, -half, half, half, 5u};                // SUB_DEPTH = 5, light.rs:187
+    uint32_t counter = 0;
+    d3 lpos = ld3(L.position), lcol = ld3(L.color);
+    while (sp > 0) {
+        Quad q = st[--sp];
+        // subdivide_points :206-218 — four jittered samples, eight draws
+        double chx = q.maxx - q.minx, chy = q.maxy - q.miny;
+        double lowx = q.minx + chx * 0.25, lowy = q.miny + chy * 0.25;
+        double highx = q.minx + chx * 0.75, highy = q.miny + chy * 0.75;
+        double cx[4] = {lowx, highx, lowx, lowx + chx * 0.5};
+        double cz[4] = {lowy + chy * 0.5, highy, lowy, lowy};
+        double rx = chx * 0.25, ry = chy * 0.25;
+        double area_porp = (q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25;   // :251
+        double s_dot[4]; d3 s_dir[4]; d3 s_int[4]; bool s_lit[4];
+        uint32_t lit_count = 0;
+        for (int s = 0; s < 4; ++s) {
+            double dx = -rx + (rx - (-rx)) * rng_light(stream, path, L.index, counter++);
+            double dz = -ry + (ry - (-ry)) * rng_light(stream, path, L.index, counter++);
+            d3 light_pos = lpos + mk3(cx[s] + dx, 0.0, cz[s] + dz);
+            d3 hit_to_light = light_pos - c.p;
+            d3 light_direction = normalize(hit_to_light);
+            double surface_dot = dot(light_direction, c.n);
+            s_lit[s] = false;
+            if (surface_dot <= 0.0) continue;
+            double light_distance = length(hit_to_light);
+            if (trace_any<COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
+            s_lit[s] = true; s_dot[s] = surface_dot; s_dir[s] = light_direction;
+            s_int[s] = lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
+            lit_count++;
+        }
+        if (q.depth == 1 || lit_count == 0) {                     // :277-279
+            for (int s = 0; s < 4; ++s) if (s_lit[s]) { RT_COUNT(wk, shade_evals); phong_lit(c, s_dot[s], s_dir[s], s_int[s]); }
+        } else if (lit_count == 4) {                              // guess_illums :222-245
+            uint32_t num_illums = 1u << (2 * q.depth);
+            double ap = 4.0 * area_porp / (double)num_illums;
+            for (uint32_t i = 0; i < num_illums; ++i) {
+                double sx = q.minx + (q.maxx - q.minx) * rng_light(stream, path, L.index, counter++);
+                double sz = q.miny + (q.maxy - q.miny) * rng_light(stream, path, L.index, counter++);
+                d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - c.p;
+                double light_distance = length(hit_to_light);
+                d3 light_direction = hit_to_light / light_distance;
+                double surface_dot = dot(light_direction, c.n);
+                RT_COUNT(wk, shade_evals);
+                phong_lit(c, surface_dot, light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * ap);
+            }
+        } else {                                                  // :284-297, children pushed in reverse visiting order
+            double hx = (q.maxx - q.minx) * 0.5, hy = (q.maxy - q.miny) * 0.5;
+            double midx = q.minx + hx, midy = q.miny + hy;
+            if (sp + 4 <= 16) {
+                st[sp++] = Quad{q.minx + hx, q.miny, q.maxx, q.maxy - hy, q.depth - 1};   // (bot, right)
+                st[sp++] = Quad{q.minx, q.miny, midx, midy, q.depth - 1};                 // (min, mid)
+                st[sp++] = Quad{midx, midy, q.maxx, q.maxy, q.depth - 1};                 // (mid, max)
+                st[sp++] = Quad{q.minx, q.miny + hy, q.maxx - hx, q.maxy, q.depth - 1};   // (left, top)
+            }
+        }
+    }
+}
+
+template <bool COUNT>
+RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
+    PhongCtx c;
+    c.p = p; c.n = n; c.view = -1.0 * ray_dir;
+    c.diffuse = ld3(sh.p); c.specular = ld3(sh.p + 3); c.shininess = sh.p[9];
+    c.total = ld3(sh.p + 6) * ld3(sc.ambient);                    // phong.rs:32
+    for (uint32_t li = 0; li < sc.num_lights; ++li) {
+        const DLight& L = sc.lights[li];
+        if (L.kind == 0) {                                        // PointLight through Lightable::get_illums_at, light.rs:17-44,140-148
+            d3 hit_to_light = ld3(L.position) - p;
+            d3 light_direction = normalize(hit_to_light);
+            double surface_dot = dot(light_direction, n);
+            if (surface_dot <= 0.0) continue;
+            double light_distance = length(hit_to_light);
+            if (trace_any<COUNT>(sc, p, light_direction, light_distance, wk)) continue;
+            d3 intensity = (L.power * ld3(L.color)) / (L.falloff[0] + L.falloff[1] * light_distance + L.falloff[2] * light_distance * light_distance) / 1.0;
+            RT_COUNT(wk, shade_evals);
+            phong_lit(c, surface_dot, light_direction, intensity);
+        } else if (L.kind == 1) {
+            square_light<COUNT>(sc, L, c, stream, path, wk);
+        } else {                                                  // DirectionLight, light.rs:104-119
+            d3 dir = ld3(L.position);
+            double surface_dot = dot(dir, n);
+            if (surface_dot <= 0.0) continue;
+            if (trace_any<COUNT>(sc, p, -1.0 * dir, INFINITY, wk)) continue;
+            RT_COUNT(wk, shade_evals);
+            phong_lit(c, surface_dot, -1.0 * dir, ld3(L.color) * L.power);
+        }
+    }
+    return c.total;
+}
+
+// ------------------------------------------------------------------ secondary-ray construction (src/geometry/ray.rs)
+RT_DEV d3 reflect_dir(d3 d, d3 n) { return normalize(d - 2.0 * dot(d, n) * n); }   // :38-53
+RT_DEV d3 transmit_dir(d3 d, d3 n, double refractive_index) {                    // :56-84
+    double incident_cos = dot(d, n);
+    if (incident_cos < 0.0) { incident_cos = -incident_cos; refractive_index = 1.0 / refractive_index; }
+    else n = n * -1.0;
+    double refraction_factor = 1.0 - refractive_index * refractive_index * (1.0 - incident_cos * incident_cos);
+    if (refraction_factor < 0.0) return reflect_dir(d, n);
+    return refractive_index * d + (refractive_index * incident_cos - sqrt(refraction_factor)) * n;
+}
+RT_DEV void fresnel(d3 d, d3 n, double ior, double& kt, double& kr) {             // translucent.rs:19-46
+    double cosi = dot(d, n);
+    double etai = 1.0, etat = ior;
+    if (cosi > 0.0) { double t = etai; etai = etat; etat = t; }
+    double sint = etai / etat * sqrt(fmax(1.0 - cosi * cosi, 0.0));
+    if (sint >= 1.0) { kt = 0.0; kr = 1.0; return; }
+    double cost = sqrt(fmax(1.0 - sint * sint, 0.0));
+    cosi = fabs(cosi);
+    double rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    double rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    double reflectance = (rs * rs + rp * rp) * 0.5;
+    kt = 1.0 - reflectance; kr = reflectance;
+}
+
+// ------------------------------------------------------------------ shader-tree interpreter
+// Walks the material of a hit depth-first, left to right — the order in which the
+// reference's nested get_color calls run — and returns L; spawned rays go to `spawn`.
+template <bool COUNT>
+RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit, d3 ray_dir, d3 ray_contrib,
+                    uint64_t stream, uint32_t path, Spawn* spawn, uint32_t& nspawn, Work<COUNT>& wk) {
+    struct Frame {
+        uint32_t shader, cursor, spawn_begin, child_spawn_begin;
+        d3 acc;          // MIX: running product; COMPOSITE: running sum (local parts)
+        d3 cin;          // contribution handed to this group
+        d3 saved_n;      // CHAIN: normal to restore on exit
+    };
+    Frame fr[RT_SHADE_MAX_FRAMES];
+    int depth = 0;
+    d3 n = hit.n;
+    nspawn = 0;
+    uint32_t cur = root_shader;
+    d3 cin = ray_contrib;
+    d3 value = mk3(0.0, 0.0, 0.0);
+    for (;;) {
+        // ---- enter `cur` with contribution `cin`
+        const DShader& sh = sc.shaders[cur];
+        bool returned = true;
+        switch (sh.kind) {
+            case DS_PHONG: value = phong_color<COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, wk); break;
+            case DS_TEXTURE: value = texture_color(sc, sh.ref, hit.u, hit.v); break;           // shader/texture.rs:16-19
+            case DS_NORMAL_MAP: value = perturbed_normal(sc, sc.normal_maps[sh.ref], hit.u, hit.v, n, hit.tangent); break;   // shader.rs:170-173
+            case DS_REFLECTION: {                                                             // shader/reflection.rs:14-18
+                d3 k = ld3(sh.p);
+                if (nspawn < RT_SHADE_MAX_SPAWN) {
+                    Spawn& s = spawn[nspawn++];
+                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = k; s.c = cin * k; s.ordinal = cur * 4 + 0;
+                }
+                value = mk3(0.0, 0.0, 0.0);
+                break;
+            }
+            case DS_TRANSLUCENT: {                                                            // shader/translucent.rs:50-62
+                double kt, kr;
+                fresnel(ray_dir, n, sh.p[3], kt, kr);
+                if (kt > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
+                    Spawn& s = spawn[nspawn++];
+                    s.o = hit.p; s.d = transmit_dir(ray_dir, n, sh.p[3]); s.w = mk3(kt, kt, kt); s.c = cin * kt; s.ordinal = cur * 4 + 1;
+                }
+                if (kr > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
+                    Spawn& s = spawn[nspawn++];
+                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = mk3(kr, kr, kr); s.c = cin * kr; s.ordinal = cur * 4 + 2;
+                }
+                value = mk3(0.0, 0.0, 0.0);
+                break;
+            }
+            default: {   // group shaders open a frame and descend into their first child
+                if (depth >= RT_SHADE_MAX_FRAMES || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
+                Frame& f = fr[depth++];
+                f.shader = cur; f.cursor = 0; f.spawn_begin = nspawn; f.child_spawn_begin = nspawn; f.cin = cin; f.saved_n = n;
+                if (sh.kind == DS_MIX) {                                                      // shader.rs:66-69
+                    f.acc = mk3(1.0, 1.0, 1.0);
+                    cur = sc.shader_child_idx[sh.first_child];
+                    cin = f.cin * f.acc;
+                } else if (sh.kind == DS_COMPOSITE) {                                         // shader.rs:95-102
+                    f.acc = mk3(0.0, 0.0, 0.0);
+                    cur = sc.shader_child_idx[sh.first_child];
+                    cin = f.cin * sc.shader_child_weight[sh.first_child];
+                } else {                                                                      // CHAIN shader.rs:134-152
+                    for (uint32_t k = 0; k < sh.nm_count; ++k)
+                        n = perturbed_normal(sc, sc.normal_maps[sc.chain_nmaps[sh.nm_begin + k]], hit.u, hit.v, n, hit.tangent);
+                    f.cursor = sh.num_children - 1;
+                    cur = sc.shader_child_idx[sh.first_child + sh.num_children - 1];
+                    cin = f.cin;
+                }
+                returned = false;
+                break;
+            }
+        }
+        if (!returned) continue;
+        // ---- `value` (+ spawns since child_spawn_begin) returns to the enclosing frames
+        for (;;) {
+            if (depth == 0) return value;
+            Frame& f = fr[depth - 1];
+            const DShader& g = sc.shaders[f.shader];
+            if (g.kind == DS_MIX) {
+                // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc
+                for (uint32_t i = f.spawn_begin; i < f.child_spawn_begin; ++i) spawn[i].w = spawn[i].w * value;
+                for (uint32_t i = f.child_spawn_begin; i < nspawn; ++i) spawn[i].w = spawn[i].w * f.acc;
+                f.acc = f.acc * value;
+            } else if (g.kind == DS_COMPOSITE) {
+                double w = sc.shader_child_weight[g.first_child + f.cursor];
+                for (uint32_t i = f.child_spawn_begin; i < nspawn; ++i) spawn[i].w = spawn[i].w * w;
+                f.acc = f.acc + w * value;
+            } else {
+                f.acc = value;
+            }
+            f.cursor++;
+            if (g.kind != DS_CHAIN && f.cursor < g.num_children) {   // next sibling
+                f.child_spawn_begin = nspawn;
+                cur = sc.shader_child_idx[g.first_child + f.cursor];
+                cin = g.kind == DS_MIX ? f.cin * f.acc : f.cin * sc.shader_child_weight[g.first_child + f.cursor];
+                break;
+            }
+            value = f.acc;                                           // group finished
+            n = f.saved_n;
+            depth--;
+        }
+    }
+}

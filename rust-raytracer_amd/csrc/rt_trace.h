@@ -1,0 +1,602 @@
+// rt_trace.h — device-side geometry: ray/primitive intersection, the mesh BVH walk,
+// the CSG interval engine and the two scene queries (closest hit, any hit).
+//
+// Everything is f64 like the reference.  Each routine cites the reference code whose
+// results it must reproduce; the control structure is different on purpose:
+//   * one flat loop over instances with composed transforms instead of the recursive
+//     SceneNode::trace (src/scene.rs:196-225);
+//   * hit records are kept minimal (distance + two ids) while searching, and the full
+//     Intersect (point, normal, tangent, uv) is rebuilt once for the winner;
+//   * meshes are walked with an explicit stack over a 2-wide BVH;
+//   * composite shapes run a postfix program over fixed-capacity hit lists.
+#pragma once
+#include "rt_math.h"
+
+#define RT_MIN_DISTANCE 0.001        // Ray::MIN_DISTANCE, src/geometry/ray.rs:12
+#define RT_MIN_CONTRIBUTION 0.003    // Ray::MIN_CONTRIBUTION, src/geometry/ray.rs:13
+#define RT_PI 3.14159265358979323846
+
+struct LRay {            // a ray in some local space, direction normalised (ray.rs:90-97)
+    d3 o, d;
+};
+
+struct Cand {            // candidate hit in the primitive's own space
+    double t;
+    uint32_t a;          // primitive-specific id: sphere root, face, plane, triangle, csg leaf
+    uint32_t b;          // bit 0: normal inverted; bits 8..: csg hit index
+};
+
+struct Details {         // Intersect fields in the primitive's own space (geometry/intersect.rs:4-11)
+    d3 p, n, tangent;
+    double u, v;
+};
+
+template <bool COUNT>
+struct Work {            // per-thread work counters, compiled out when COUNT is false
+    unsigned long long instance_tests, box_tests, tri_tests, shade_evals, rays_shadow, rays_secondary, stack_overflows;
+};
+
+#define RT_COUNT(w, field) do { if (COUNT) (w).field++; } while (0)
+
+// world/parent ray → local ray; returns s = |M_lin d| (local length of a unit parent step)
+RT_DEV LRay to_local(const DXform& x, d3 o, d3 d, double& s, double& inv_s) {
+    LRay r;
+    r.o = xf_point(x.w2l, o);
+    d3 v = xf_vector(x.w2l, d);
+    if (x.uniform_inv_s != 0.0) { inv_s = x.uniform_inv_s; s = x.uniform_s; }
+    else { s = length(v); inv_s = 1.0 / s; }
+    r.d = v * inv_s;
+    return r;
+}
+
+// ------------------------------------------------------------------ sphere (src/primitive/sphere.rs)
+// two_intersects :31-44; n = number of valid roots (t >= MIN_DISTANCE, :47), ascending
+RT_DEV int sphere_roots(double radius, const LRay& r, double t[2], uint32_t which[2]) {
+    d3 l = neg(r.o);
+    double adj = dot(l, r.d);
+    double d2 = dot(l, l) - (adj * adj);
+    double radius2 = radius * radius;
+    if (d2 > radius2) return 0;
+    double thc = sqrt(radius2 - d2);
+    double t0 = adj - thc, t1 = adj + thc;
+    int n = 0;
+    if (!(t0 < RT_MIN_DISTANCE)) { t[n] = t0; which[n] = 0; ++n; }
+    if (!(t1 < RT_MIN_DISTANCE)) { t[n] = t1; which[n] = 1; ++n; }
+    return n;
+}
+RT_DEV void sphere_details(const LRay& r, double t, Details& o) {   // :18-29, :51-56
+    o.p = r.o + (t * r.d);
+    d3 hn = normalize(o.p);
+    double azimuth = atan2(hn.z, hn.x);
+    double elevation = asin(hn.y);
+    surface_coord((azimuth / 2.0) / RT_PI + 0.5, elevation / RT_PI + 0.5, o.u, o.v);
+    o.n = hn;
+    o.tangent = cross(hn, cross(mk3(0.0, 1.0, 0.0), hn));
+}
+
+// ------------------------------------------------------------------ rectangle / plane / triangle / polygon (src/primitive/plane.rs)
+RT_DEV bool rect_hit(double w, double h, const LRay& r, double& t) {   // :77-90
+    double hit_distance = r.o.z / r.d.z * -1.0;
+    d3 p = r.o + (hit_distance * r.d);
+    double hb = w / 2.0, vb = h / 2.0;
+    if (hit_distance < RT_MIN_DISTANCE || p.x < -hb || p.x > hb || p.y < -vb || p.y > vb) return false;
+    if (!(hit_distance == hit_distance)) return false;   // 0/0: origin in the plane and direction parallel to it
+    t = hit_distance;
+    return true;
+}
+RT_DEV void rect_details(double w, double h, const LRay& r, double t, Details& o) {   // :91-96
+    o.p = r.o + (t * r.d);
+    double hb = w / 2.0, vb = h / 2.0;
+    surface_coord((o.p.x / hb + 1.0) / 2.0, (o.p.y / vb + 1.0) / 2.0, o.u, o.v);
+    o.n = mk3(0.0, 0.0, 1.0);
+    o.tangent = mk3(0.0, 1.0, 0.0);
+}
+RT_DEV bool plane_hit(const double* p, const LRay& r, double& t) {     // :46-60
+    d3 origin = ld3(p), normal = ld3(p + 3);
+    double origin_dot = dot(normal, r.o - origin);
+    double direction_dot = dot(normal, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance >= RT_MIN_DISTANCE) { t = hit_distance; return true; }
+    return false;
+}
+RT_DEV void plane_details(const double* p, const LRay& r, double t, Details& o) {   // :37-42, :55
+    d3 origin = ld3(p), tangent = ld3(p + 6);
+    o.p = r.o + (t * r.d);
+    d3 a = o.p - origin;
+    d3 v = (dot(a, tangent) / dot(tangent, tangent)) * tangent;
+    d3 u = a - v;
+    surface_coord(fract_(length(u) / p[9]), fract_(length(v) / p[10]), o.u, o.v);
+    o.n = ld3(p + 3);
+    o.tangent = tangent;
+}
+RT_DEV bool tri_hit(const DTri& tr, const LRay& r, double& t) {        // :141-164
+    d3 n = ld3(tr.n);
+    double origin_dot = dot(n, r.o - ld3(tr.v));
+    double direction_dot = dot(n, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        if (dot(cross(ld3(tr.e), p - ld3(tr.v)), n) >= 0.0 && dot(cross(ld3(tr.e + 3), p - ld3(tr.v + 3)), n) >= 0.0 &&
+            dot(cross(ld3(tr.e + 6), p - ld3(tr.v + 6)), n) >= 0.0) {
+            t = hit_distance;
+            return true;
+        }
+    }
+    return false;
+}
+RT_DEV void tri_details(const DTri& tr, const LRay& r, double t, Details& o) {   // :129-136, :158-159
+    o.p = r.o + (t * r.d);
+    double side_a = length(o.p - ld3(tr.v)), side_b = length(o.p - ld3(tr.v + 3));
+    double side_c = tr.side_c;
+    double cos_theta = (side_c * side_c + side_a * side_a - side_b * side_b) / (2.0 * side_c * side_a);
+    double x = side_a * cos_theta;
+    double y = sqrt(side_a * side_a - x * x);
+    surface_coord(x / tr.sc_width, y / tr.sc_height, o.u, o.v);
+    o.n = ld3(tr.n);
+    o.tangent = ld3(tr.tangent);
+}
+RT_DEV bool poly_hit(const DScene& sc, const DPoly& pl, const LRay& r, double& t) {   // :207-234
+    d3 n = ld3(pl.n);
+    const double* V = sc.points + 3 * (size_t)pl.first_vertex;
+    const double* E = sc.points + 3 * (size_t)pl.first_edge;
+    double origin_dot = dot(n, r.o - ld3(V));
+    double direction_dot = dot(n, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        for (uint32_t i = 0; i < pl.count; ++i)
+            if (!(dot(cross(ld3(E + 3 * i), p - ld3(V + 3 * i)), n) >= 0.0)) return false;
+        t = hit_distance;
+        return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ Cube / Tetrahedron (src/primitive/cube.rs:40-69, 131-163)
+// Faces are tested in the reference's order; the first two valid faces are kept, ordered
+// by distance in the solid's space, and the loop stops at the second.
+RT_DEV int faced_hits(const DScene& sc, const DFaced& f, const LRay& r, double t[2], uint32_t face[2]) {
+    int n = 0;
+    for (uint32_t i = 0; i < f.nfaces; ++i) {
+        double s, inv_s;
+        LRay fr = to_local(f.face[i], r.o, r.d, s, inv_s);
+        double tf;
+        bool hit = f.base_is_triangle ? tri_hit(sc.tris[f.base_tri], fr, tf) : rect_hit(f.base_w, f.base_h, fr, tf);
+        if (!hit) continue;
+        d3 p = xf_point(f.face[i].l2w, fr.o + (tf * fr.d));
+        double dist = length(p - r.o);                           // intersect.rs:34
+        if (!(dist >= RT_MIN_DISTANCE)) continue;
+        if (n == 0) { t[0] = dist; face[0] = i; n = 1; }
+        else {
+            if (dist < t[0]) { t[1] = t[0]; face[1] = face[0]; t[0] = dist; face[0] = i; }
+            else { t[1] = dist; face[1] = i; }
+            n = 2;
+            break;
+        }
+    }
+    return n;
+}
+RT_DEV void faced_details(const DScene& sc, const DFaced& f, const LRay& r, uint32_t i, Details& o) {
+    double s, inv_s, tf = 0.0;
+    LRay fr = to_local(f.face[i], r.o, r.d, s, inv_s);
+    Details b;
+    if (f.base_is_triangle) { tri_hit(sc.tris[f.base_tri], fr, tf); tri_details(sc.tris[f.base_tri], fr, tf, b); }
+    else { rect_hit(f.base_w, f.base_h, fr, tf); rect_details(f.base_w, f.base_h, fr, tf, b); }
+    o.p = xf_point(f.face[i].l2w, b.p);
+    o.n = xf_normal(f.face[i].nmat, b.n);
+    o.tangent = xf_vector(f.face[i].l2w, b.tangent);
+    if (f.is_cube) {                                             // cube.rs:12, 33-38
+        const double off_u[6] = {2.0, 0.0, 1.0, 3.0, 1.0, 1.0}, off_v[6] = {1.0, 1.0, 1.0, 1.0, 2.0, 0.0};
+        surface_coord((b.u + off_u[i]) / 4.0, (b.v + off_v[i]) / 3.0, o.u, o.v);
+    } else {                                                     // cube.rs:124-129
+        surface_coord((b.u + (double)i / 2.0) / 2.5, 1.0 - b.v, o.u, o.v);
+    }
+}
+
+// ------------------------------------------------------------------ Polyhedron (src/primitive/polyhedron.rs:99-136)
+RT_DEV bool polyhedron_hit(const DScene& sc, const DPrim& ph, const LRay& r, double& t, uint32_t& plane) {
+    bool found = false;
+    for (uint32_t i = 0; i < ph.count; ++i) {
+        const double* pp = sc.prims[ph.ref + i].p;
+        double ti;
+        if (!plane_hit(pp, r, ti)) continue;
+        d3 p = r.o + (ti * r.d);
+        bool inside = true;
+        for (uint32_t k = 1; k < ph.count; ++k) {
+            const double* q = sc.prims[ph.ref + (k + i) % ph.count].p;
+            if (dot(ld3(q) - p, ld3(q + 3)) < 0.0) { inside = false; break; }
+        }
+        if (!inside) continue;
+        if (!found || ti < t) { t = ti; plane = i; found = true; }
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------ mesh (src/mesh.rs)
+// Mesh::check_triangle :416-447 without the attribute interpolation: distance only.
+RT_DEV bool mesh_tri_hit(const DMeshTri& tr, const LRay& r, double& t) {
+    d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3), normal = ld3(tr.n);
+    double origin_dot = dot(normal, r.o - v1);
+    double direction_dot = dot(normal, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        if (dot(cross(v2 - v1, p - v1), normal) < 0.0) return false;
+        if (dot(cross(v3 - v2, p - v2), normal) < 0.0) return false;
+        if (dot(cross(v1 - v3, p - v3), normal) < 0.0) return false;
+        t = hit_distance;
+        return true;
+    }
+    return false;
+}
+RT_DEV void mesh_details(const DScene& sc, const DMesh& m, const DMeshTri& tr, const LRay& r, double t, Details& o) {   // :429-462
+    d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3);
+    o.p = r.o + (t * r.d);
+    d3 vv = cross(v2 - v1, o.p - v1);
+    d3 uu = cross(v1 - v3, o.p - v3);
+    double u = length(uu) * tr.inv_area;
+    double v = length(vv) * tr.inv_area;
+    double w = 1.0 - u - v;
+    if (m.num_normals > tr.i1) {
+        const double* N = sc.mesh_normals + 3 * (size_t)m.normal_off;
+        o.n = w * ld3(N + 3 * (size_t)tr.i1) + u * ld3(N + 3 * (size_t)tr.i2) + v * ld3(N + 3 * (size_t)tr.i3);
+    } else {
+        o.n = ld3(tr.n);
+    }
+    if (m.num_uvs > tr.i1) {
+        const double* T = sc.mesh_uvs + 2 * (size_t)m.uv_off;
+        double tx = (T[2 * (size_t)tr.i1] * w + T[2 * (size_t)tr.i2] * u) + T[2 * (size_t)tr.i3] * v;
+        double ty = (T[2 * (size_t)tr.i1 + 1] * w + T[2 * (size_t)tr.i2 + 1] * u) + T[2 * (size_t)tr.i3 + 1] * v;
+        surface_coord(tx, ty, o.u, o.v);
+    } else {
+        surface_coord(0.0, 0.0, o.u, o.v);
+    }
+    o.tangent = mk3(0.0, 1.0, 0.0);
+}
+
+RT_DEV bool slab(const double* lo, const double* hi, d3 o, d3 inv, double tmax, double& tnear) {
+    double t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+    double tn = fmin(t0, t1), tf = fmax(t0, t1);
+    t0 = (lo[1] - o.y) * inv.y; t1 = (hi[1] - o.y) * inv.y;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    t0 = (lo[2] - o.z) * inv.z; t1 = (hi[2] - o.z) * inv.z;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    tnear = tn;
+    return tn <= tf && tf >= 0.0 && tn <= tmax;
+}
+
+// Closest triangle with t in (MIN_DISTANCE, tmax) [strict upper bound when !ANY], or —
+// with ANY — whether some triangle has t <= tmax (INCLUSIVE) / t < tmax.
+// Replaces BoundingNode::check_intersect (mesh.rs:167-279); the result is the same
+// closest hit because both structures are exact.
+template <bool ANY, bool COUNT>
+RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, double tmax, bool inclusive, double& t_out, uint32_t& tri_out, Work<COUNT>& wk) {
+    d3 inv = mk3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    double tn;
+    RT_COUNT(wk, box_tests);
+    if (!slab(m.lo, m.hi, r.o, inv, tmax, tn)) return false;
+    const DBvhNode* nodes = sc.bvh_nodes + m.node_off;
+    const DMeshTri* tris = sc.mesh_tris + m.tri_off;
+    uint32_t stack[RT_BVH_STACK];
+    int sp = 0;
+    uint32_t cur = 0;
+    bool found = false;
+    double best = tmax;
+    for (;;) {
+        const DBvhNode& n = nodes[cur];
+        double tn0, tn1;
+        if (COUNT) wk.box_tests += 2;
+        bool h0 = slab(n.lo[0], n.hi[0], r.o, inv, best, tn0);
+        bool h1 = slab(n.lo[1], n.hi[1], r.o, inv, best, tn1);
+        uint32_t next = 0xFFFFFFFFu;
+        // visit order: nearer child first
+        int first = (h0 && h1 && tn1 < tn0) ? 1 : 0;
+        for (int k = 0; k < 2; ++k) {
+            int c = k == 0 ? first : 1 - first;
+            bool h = c == 0 ? h0 : h1;
+            if (!h) continue;
+            uint32_t ref = n.child[c];
+            if (ref & 0x80000000u) {
+                uint32_t base = ref & 0x7FFFFFFFu, cnt = n.count[c];
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    double t;
+                    RT_COUNT(wk, tri_tests);
+                    if (mesh_tri_hit(tris[base + i], r, t)) {
+                        if (ANY) {
+                            if (inclusive ? t <= tmax : t < tmax) return true;
+                        } else if (t < best) {
+                            best = t; tri_out = base + i; found = true;
+                        }
+                    }
+                }
+            } else if (next == 0xFFFFFFFFu) {
+                next = ref;
+            } else {
+                if (sp < RT_BVH_STACK) stack[sp++] = ref;
+            }
+        }
+        if (next != 0xFFFFFFFFu) { cur = next; continue; }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    t_out = best;
+    return found;
+}
+
+// ------------------------------------------------------------------ basic (non-composite) primitives
+// get_all_intersects of a primitive without wrappers: up to two hits, ascending.
+template <bool COUNT>
+RT_DEV int basic_hits(const DScene& sc, const DPrim& p, const LRay& r, double tmax_closest, Cand c[2], Work<COUNT>& wk) {
+    switch (p.kind) {
+        case DP_SPHERE: {
+            double t[2]; uint32_t w[2];
+            int n = sphere_roots(p.p[0], r, t, w);
+            for (int i = 0; i < n; ++i) { c[i].t = t[i]; c[i].a = w[i]; c[i].b = 0; }
+            return n;
+        }
+        case DP_RECTANGLE: { c[0].a = 0; c[0].b = 0; return rect_hit(p.p[0], p.p[1], r, c[0].t) ? 1 : 0; }
+        case DP_PLANE: { c[0].a = 0; c[0].b = 0; return plane_hit(p.p, r, c[0].t) ? 1 : 0; }
+        case DP_TRIANGLE: { c[0].a = 0; c[0].b = 0; return tri_hit(sc.tris[p.ref], r, c[0].t) ? 1 : 0; }
+        case DP_POLYGON: { c[0].a = 0; c[0].b = 0; return poly_hit(sc, sc.polys[p.ref], r, c[0].t) ? 1 : 0; }
+        case DP_FACED: {
+            double t[2]; uint32_t f[2];
+            int n = faced_hits(sc, sc.faced[p.ref], r, t, f);
+            for (int i = 0; i < n; ++i) { c[i].t = t[i]; c[i].a = f[i]; c[i].b = 0; }
+            return n;
+        }
+        case DP_POLYHEDRON: { c[0].b = 0; return polyhedron_hit(sc, p, r, c[0].t, c[0].a) ? 1 : 0; }
+        case DP_MESH: {
+            c[0].b = 0;
+            return mesh_walk<false, COUNT>(sc, sc.meshes[p.ref], r, tmax_closest, false, c[0].t, c[0].a, wk) ? 1 : 0;
+        }
+        default: return 0;
+    }
+}
+RT_DEV void basic_details(const DScene& sc, const DPrim& p, const LRay& r, const Cand& c, Details& o) {
+    switch (p.kind) {
+        case DP_SPHERE: sphere_details(r, c.t, o); break;
+        case DP_RECTANGLE: rect_details(p.p[0], p.p[1], r, c.t, o); break;
+        case DP_PLANE: plane_details(p.p, r, c.t, o); break;
+        case DP_TRIANGLE: tri_details(sc.tris[p.ref], r, c.t, o); break;
+        case DP_POLYGON:
+            o.p = r.o + (c.t * r.d); o.n = ld3(sc.polys[p.ref].n); o.tangent = mk3(0.0, 1.0, 0.0);
+            surface_coord(0.0, 0.0, o.u, o.v);
+            break;
+        case DP_FACED: faced_details(sc, sc.faced[p.ref], r, c.a, o); break;
+        case DP_POLYHEDRON: {
+            plane_details(sc.prims[p.ref + c.a].p, r, c.t, o);
+            surface_coord(((double)c.a + o.u) / (double)p.count, o.v, o.u, o.v);   // polyhedron.rs:109-113
+            break;
+        }
+        case DP_MESH: {
+            const DMesh& m = sc.meshes[p.ref];
+            mesh_details(sc, m, sc.mesh_tris[m.tri_off + c.a], r, c.t, o);
+            break;
+        }
+        default: break;
+    }
+    if (c.b & 1u) o.n = neg(o.n);
+}
+// n·d sign of a candidate, the quantity OneWay / Inverted / hit_direction test
+RT_DEV double facing(const DScene& sc, const DPrim& p, const LRay& r, const Cand& c) {
+    if (p.kind == DP_SPHERE && !(c.b & 1u)) return dot(r.d, r.o + (c.t * r.d));   // same sign as d·normalize(p)
+    Details d;
+    basic_details(sc, p, r, c, d);
+    return dot(r.d, d.n);
+}
+// Apply the OneWay / Inverted chain to a *closest* hit (src/primitive.rs:33-40, 64-72).
+RT_DEV bool wrap_closest(const DScene& sc, const DPrim& p, const LRay& r, Cand& c) {
+    for (uint32_t w = p.wrap; w; w >>= 2) {
+        double f = facing(sc, p, r, c);
+        if ((w & 3u) == DWRAP_ONEWAY) { if (!(f < 0.0)) return false; }
+        else { if (!(f >= 0.0)) return false; c.b ^= 1u; }
+    }
+    return true;
+}
+// Apply the chain to a get_all_intersects list (src/primitive.rs:42-45, 74-80): OneWay
+// filters, Inverted flips every normal without filtering.
+RT_DEV int wrap_all(const DScene& sc, const DPrim& p, const LRay& r, Cand c[2], int n) {
+    for (uint32_t w = p.wrap; w; w >>= 2) {
+        if ((w & 3u) == DWRAP_ONEWAY) {
+            int m = 0;
+            for (int i = 0; i < n; ++i) if (facing(sc, p, r, c[i]) < 0.0) c[m++] = c[i];
+            n = m;
+        } else {
+            for (int i = 0; i < n; ++i) c[i].b ^= 1u;
+        }
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ CSG (src/composite_shape.rs:75-123 + shape files)
+struct CsgHit {
+    double t;            // distance along the ray in the composite's parent space
+    uint32_t leaf;       // csg_leaves index
+    uint32_t meta;       // bit0 enter, bit1 inverted, bits 8..15 hit index within the leaf, bit 2 leaf cand.b bit0
+};
+RT_DEV int csg_predicate(uint32_t kind, uint32_t cur, uint32_t states, uint32_t n) {   // 0 skip, 1 emit, 2 emit inverted
+    bool s0 = states & 1u, s1 = states & 2u;
+    switch (kind) {
+        case DC_SUBTRACT:                                          // subtract_shape.rs:46-53
+            if (!s1 && cur == 0) return 1;
+            if (s0 && cur == 1) return 2;
+            return 0;
+        case DC_AND: return (((states >> (1 - cur)) & 1u) || (s0 && s1)) ? 1 : 0;   // and_shape.rs:25
+        case DC_MULTI_AND: {                                       // and_shape.rs:93
+            uint32_t all = (1u << n) - 1u;
+            return ((states | (1u << cur)) & all) == all ? 1 : 0;
+        }
+        case DC_OR: return (!(s0 && s1) && ((!s0 && !s1) || ((states >> cur) & 1u))) ? 1 : 0;   // or_shape.rs:25-27
+        case DC_XOR:                                               // xor_shape.rs:25-33
+            if (!s0 && !s1) return 1;
+            if ((s0 && s1) || ((states >> (1 - cur)) & 1u)) return 2;
+            return 1;
+    }
+    return 0;
+}
+template <bool COUNT>
+RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, Cand& out, Work<COUNT>& wk) {
+    CsgHit arena[RT_CSG_ARENA];
+    uint32_t lbegin[RT_CSG_MAX_LISTS], lcount[RT_CSG_MAX_LISTS];
+    uint32_t nl = 0, top = 0;
+    for (uint32_t oi = 0; oi < root.op_count; ++oi) {
+        const DCsgOp& op = sc.csg_ops[root.op_begin + oi];
+        if (op.kind == DC_BASE) {                                  // BaseShape::get_all_intersects, base_shape.rs:49-53
+            const DCsgLeaf& leaf = sc.csg_leaves[op.leaf];
+            const DPrim& p = sc.prims[leaf.prim];
+            double s, inv_s;
+            LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
+            Cand c[2];
+            int n = basic_hits<COUNT>(sc, p, lr, INFINITY, c, wk);
+            if (p.wrap) n = wrap_all(sc, p, lr, c, n);
+            lbegin[nl] = top; lcount[nl] = 0;
+            for (int i = 0; i < n && top < RT_CSG_ARENA; ++i) {
+                CsgHit h;
+                h.t = c[i].t * inv_s;
+                h.leaf = op.leaf;
+                bool enter = facing(sc, p, lr, c[i]) < 0.0;        // hit_direction, composite_shape.rs:27-30
+                h.meta = (enter ? 1u : 0u) | ((c[i].b & 1u) << 2) | ((uint32_t)i << 8);
+                arena[top++] = h; lcount[nl]++;
+            }
+            ++nl;
+        } else {
+            uint32_t k = op.num_children, base = nl - k;
+            CsgHit outl[RT_CSG_MAX_HITS];
+            uint32_t no = 0, states = 0, cursor[8];
+            for (uint32_t i = 0; i < k; ++i) {                     // initial inside-state from the first hit, :99-109
+                cursor[i] = 0;
+                if (lcount[base + i] > 0 && !(arena[lbegin[base + i]].meta & 1u)) states |= 1u << i;
+            }
+            for (;;) {                                             // fold of pairwise merges, ties → later list, :33-72, :111
+                int pick = -1; double bt = 0.0;
+                for (uint32_t i = 0; i < k; ++i) {
+                    if (cursor[i] >= lcount[base + i]) continue;
+                    double t = arena[lbegin[base + i] + cursor[i]].t;
+                    if (pick < 0 || !(bt < t)) { pick = (int)i; bt = t; }
+                }
+                if (pick < 0) break;
+                CsgHit h = arena[lbegin[base + pick] + cursor[pick]++];
+                int pr = csg_predicate(op.kind, (uint32_t)pick, states, k);
+                if (pr && no < RT_CSG_MAX_HITS) {
+                    if (pr == 2) h.meta ^= 3u;                     // invert_normal flips the facing too
+                    outl[no++] = h;
+                }
+                states ^= 1u << pick;
+            }
+            top = lbegin[base];
+            for (uint32_t i = 0; i < no; ++i) arena[top + i] = outl[i];
+            lcount[base] = no; top += no;
+            nl = base + 1;
+        }
+    }
+    if (nl == 0 || lcount[0] == 0) return false;
+    const CsgHit& h = arena[lbegin[0]];
+    out.t = h.t;
+    out.a = h.leaf;
+    out.b = ((h.meta >> 1) & 1u) | (((h.meta >> 2) & 1u) << 1) | ((h.meta >> 8) << 8);
+    return true;
+}
+template <bool COUNT>
+RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details& o, Work<COUNT>& wk) {
+    const DCsgLeaf& leaf = sc.csg_leaves[c.a];
+    const DPrim& p = sc.prims[leaf.prim];
+    double s, inv_s;
+    LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
+    Cand lc[2];
+    Work<false> none;
+    int n = basic_hits<false>(sc, p, lr, INFINITY, lc, none);
+    if (p.wrap) n = wrap_all(sc, p, lr, lc, n);
+    uint32_t idx = c.b >> 8;
+    Details d;
+    basic_details(sc, p, lr, lc[idx < (uint32_t)n ? idx : 0], d);
+    o.p = xf_point(leaf.x.l2w, d.p);
+    o.n = xf_normal(leaf.x.nmat, d.n);
+    if (c.b & 1u) o.n = neg(o.n);
+    o.tangent = xf_vector(leaf.x.l2w, d.tangent);
+    o.u = d.u; o.v = d.v;
+}
+
+// ------------------------------------------------------------------ scene queries
+struct SceneHit {
+    double t;            // world distance
+    uint32_t inst;
+    Cand c;              // in the instance's primitive space
+};
+
+template <bool COUNT>
+RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk) {
+    if (p.kind == DP_CSG) return csg_closest<COUNT>(sc, sc.csg_roots[p.ref], lr, c, wk);
+    Cand cc[2];
+    // an un-wrapped mesh may prune by the best distance so far; wrapped primitives must see their true closest hit
+    int n = basic_hits<COUNT>(sc, p, lr, p.wrap ? INFINITY : tmax_local, cc, wk);
+    if (n == 0) return false;
+    c = cc[0];
+    if (p.wrap) return wrap_closest(sc, p, lr, c);
+    return true;
+}
+
+// Scene::cast_ray's root.trace(ray) (src/scene.rs:68, 196-225): closest hit over all instances,
+// strict '<' with earlier instances winning ties (own primitive before children, children in order).
+template <bool COUNT>
+RT_DEV bool trace_closest(const DScene& sc, d3 o, d3 d, SceneHit& hit, Work<COUNT>& wk) {
+    bool found = false;
+    double best = INFINITY;
+    for (uint32_t i = 0; i < sc.num_instances; ++i) {
+        const DInstance& in = sc.instances[i];
+        double s, inv_s;
+        LRay lr = to_local(in.x, o, d, s, inv_s);
+        Cand c;
+        RT_COUNT(wk, instance_tests);
+        if (!prim_closest<COUNT>(sc, sc.prims[in.prim], lr, best * s, c, wk)) continue;
+        double tw = c.t * inv_s;
+        if (tw < best) { best = tw; hit.inst = i; hit.c = c; found = true; }
+    }
+    hit.t = best;
+    return found;
+}
+
+// SceneNode::partial_trace_until_distance (src/scene.rs:227-248): is anything closer than the light?
+template <bool COUNT>
+RT_DEV bool trace_any(const DScene& sc, d3 o, d3 d, double max_distance, Work<COUNT>& wk) {
+    RT_COUNT(wk, rays_shadow);
+    for (uint32_t i = 0; i < sc.num_instances; ++i) {
+        const DInstance& in = sc.instances[i];
+        const DPrim& p = sc.prims[in.prim];
+        double s, inv_s;
+        LRay lr = to_local(in.x, o, d, s, inv_s);
+        double max_local = max_distance * s;
+        RT_COUNT(wk, instance_tests);
+        if (p.kind == DP_MESH && !p.wrap) {
+            double t; uint32_t tri;
+            if (mesh_walk<true, COUNT>(sc, sc.meshes[p.ref], lr, max_local, in.is_root != 0, t, tri, wk)) return true;
+            continue;
+        }
+        Cand c;
+        if (!prim_closest<COUNT>(sc, p, lr, INFINITY, c, wk)) continue;
+        if (in.is_root ? c.t <= max_local : c.t < max_local) return true;
+    }
+    return false;
+}
+
+// Rebuild the world-space Intersect of the winning hit (geometry/intersect.rs:31-45 applied
+// through every level at once).
+struct WorldHit {
+    d3 p, n, tangent;
+    double u, v;
+    uint32_t inst;
+};
+template <bool COUNT>
+RT_DEV void world_hit(const DScene& sc, d3 o, d3 d, const SceneHit& h, WorldHit& w, Work<COUNT>& wk) {
+    const DInstance& in = sc.instances[h.inst];
+    const DPrim& p = sc.prims[in.prim];
+    double s, inv_s;
+    LRay lr = to_local(in.x, o, d, s, inv_s);
+    Details dt;
+    if (p.kind == DP_CSG) csg_details<COUNT>(sc, lr, h.c, dt, wk);
+    else basic_details(sc, p, lr, h.c, dt);
+    w.p = xf_point(in.x.l2w, dt.p);
+    w.n = xf_normal(in.x.nmat, dt.n);
+    w.tangent = xf_vector(in.x.l2w, dt.tangent);
+    w.u = dt.u; w.v = dt.v;
+    w.inst = h.inst;
+}

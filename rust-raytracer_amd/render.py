@@ -1,0 +1,117 @@
+"""ctypes binding of the HIP render path (csrc/librt_amd.so, C ABI in include/rt_amd.h).
+
+There is no CPU fallback: if the library is missing, or no gfx950 device is visible,
+the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import RT_OK, RtAux, RtCamera, RtImageDim, RtRenderConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "librt_amd.so")
+
+EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
+           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings"]
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt_amd status {code}: {msg}")
+        self.code = code
+
+
+def hip_lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"{HIP_LIB} is missing: the HIP render path was not built "
+                               f"(python -c 'import __graft_entry__ as g; g.build()')")
+        lib = C.CDLL(HIP_LIB)
+        lib.rt_device_count.restype = C.c_int
+        lib.rt_last_error.restype = C.c_char_p
+        lib.rt_scene_create.restype = C.c_int
+        lib.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.rt_scene_destroy.argtypes = [C.c_void_p]
+        lib.rt_render.restype = C.c_int
+        lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RtImageDim), C.POINTER(RtCamera), C.POINTER(RtRenderConfig),
+                                  C.c_void_p, C.POINTER(RtAux)]
+        lib.rt_render_device.restype = C.c_int
+        lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtImageDim), C.POINTER(RtCamera), C.POINTER(RtRenderConfig),
+                                         C.c_void_p, C.POINTER(RtAux), C.c_void_p]
+        lib.rt_owned_rows_capacity.restype = C.c_uint32
+        lib.rt_owned_rows_capacity.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.rt_last_timings.restype = C.c_int
+        lib.rt_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != RT_OK:
+        raise RtError(rc, hip_lib().rt_last_error().decode())
+
+
+class DeviceScene:
+    """A scene flattened and resident in HBM (rt_scene_create)."""
+
+    def __init__(self, scene, device=0):
+        lib = hip_lib()
+        self.scene = scene   # keeps the description alive
+        self.device = device
+        handle = C.c_void_p()
+        _check(lib.rt_scene_create(scene.desc, device, C.byref(handle)))
+        self._handle = handle
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def render(self, dim, cam, cfg, want_aux=True, count_work=False):
+        """rt_render: host-memory outputs as numpy arrays."""
+        lib = hip_lib()
+        w, h = dim.width, dim.height
+        rows = lib.rt_owned_rows_capacity(h, cfg.nranks, cfg.tile_rows)
+        rgb = np.zeros((rows, w, 3), dtype=np.uint8)
+        aux = RtAux()
+        out = {"rgb": rgb}
+        if want_aux:
+            out["color"] = np.zeros((h, w, 3), dtype=np.float64)
+            out["distance"] = np.zeros((h, w), dtype=np.float64)
+            out["hit_id"] = np.zeros((h, w), dtype=np.uint32)
+            out["aa_mask"] = np.zeros((h, w), dtype=np.uint8)
+            aux.color = out["color"].ctypes.data
+            aux.distance = out["distance"].ctypes.data
+            aux.hit_id = out["hit_id"].ctypes.data
+            aux.aa_mask = out["aa_mask"].ctypes.data
+        aux.count_work = 1 if count_work else 0
+        _check(lib.rt_render(self._handle, C.byref(dim), C.byref(cam), C.byref(cfg), rgb.ctypes.data, C.byref(aux)))
+        out["counters"] = aux.counters.as_dict()
+        out["ms"] = {"pass1": aux.ms_pass1, "aa": aux.ms_aa, "encode": aux.ms_encode}
+        return out
+
+    def render_device(self, dim, cam, cfg, d_rgb_ptr, stream_ptr=None, d_aux=None):
+        """rt_render_device: asynchronous, outputs stay in device memory (raw pointers)."""
+        lib = hip_lib()
+        _check(lib.rt_render_device(self._handle, C.byref(dim), C.byref(cam), C.byref(cfg), C.c_void_p(d_rgb_ptr),
+                                    C.byref(d_aux) if d_aux is not None else None,
+                                    C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def last_timings(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _check(hip_lib().rt_last_timings(self._handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pass1": a.value, "aa": b.value, "encode": c.value}
+
+    def close(self):
+        if self._handle:
+            hip_lib().rt_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
