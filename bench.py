@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: glass_monkey (tests/mesh_test.rs:96-134 of the reference) at
+1920x1080, anti-aliasing on, on N MI355X — Mrays/s and ms/frame.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One step = one full frame through the HIP render path (pass 1 over all pixels, AA detect
++ resolve, clamp/gamma/encode) and, for N > 1, the gather of the RGB8 row blocks to
+rank 0.  The scene is already resident in HBM when the timed region starts.  Rank 0
+prints one JSON line.
+
+ray        = one closest-hit query that passed the depth/contribution gate, or one any-hit
+             shadow query (counted on device by an instrumented, untimed frame)
+roofline   = FP64 vector ALU: algorithmic flops of the dominant kernel (fixed cost per
+             counted unit of work, see fill_counters in csrc/rt_api.hip) / its HIP-event
+             duration, against the 78.6 TFLOP/s FP64 vector peak
+cpu_baseline = the CPU restatement of the reference (oracle/, 8 threads like the
+             reference's default pool) on a bounded sample of the same frame
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+scenes = importlib.import_module("rust-raytracer_amd.scenes")
+render = importlib.import_module("rust-raytracer_amd.render")
+rdist = importlib.import_module("rust-raytracer_amd.dist")
+abi = importlib.import_module("rust-raytracer_amd._abi")
+
+WIDTH, HEIGHT = 1920, 1080
+SCENE = "glass_monkey"
+TILE_ROWS = 16
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, FP64 vector (half the 157.3 TF FP32 vector rate)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(scene, dim, cam, cfg):
+    """Time the CPU oracle on every 8th 16-row block of the same frame (~1/8 of the pixels)."""
+    from oracle import binding as oracle
+    c = cfg.copy()
+    c.num_threads = 8
+    c.rank, c.nranks, c.tile_rows = 3, 8, TILE_ROWS
+    t0 = time.time()
+    out = oracle.render(scene, dim, cam, c, want_aux=True, faithful_cost=True)
+    dt = time.time() - t0
+    rays = out["counters"]["rays_total"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 8, "kind": "port",
+            "sample": f"{SCENE} {WIDTH}x{HEIGHT} AA on, every 8th {TILE_ROWS}-row block "
+                      f"(+1-row AA halo): {rays} rays in {dt:.1f} s; C++ restatement of the reference CPU path "
+                      f"incl. its per-hit 4x4 inverse, 8 threads (reference default), not the Rust binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the HIP render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene = scenes.Scene(SCENE)
+    dim, cam, cfg = scene.view(width=WIDTH, height=HEIGHT, anti_alias=True, seed=1)
+    ds = render.DeviceScene(scene, device=local_rank)
+    stream = torch.cuda.current_stream(device)
+
+    # --- instrumented, untimed frames: rays and algorithmic flops of this rank's share
+    def counted(anti_alias):
+        c = cfg.copy()
+        c.anti_alias = 1 if anti_alias else 0
+        c.rank, c.nranks, c.tile_rows = rank, world, TILE_ROWS
+        cap = rdist.owned_rows_capacity(HEIGHT, world, TILE_ROWS)
+        buf = torch.zeros((cap, WIDTH, 3), dtype=torch.uint8, device=device)
+        aux = abi.RtAux()
+        aux.count_work = 1
+        ds.render_device(dim, cam, c, buf.data_ptr(), stream.cuda_stream, aux)
+        return aux.counters.as_dict()
+
+    full = counted(True)
+    p1 = counted(False)
+    rays_local = full["rays_total"]
+    flops_pass1 = p1["flops"]
+    flops_aa = full["flops"] - p1["flops"]
+    t = torch.tensor([rays_local, flops_pass1, flops_aa, full["stack_overflows"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t)
+    rays_total = float(t[0].item())
+    if t[3].item() != 0:
+        raise RuntimeError("secondary-ray stack overflowed: results would be incomplete")
+
+    # --- timed region
+    local_fn = rdist.hip_render_local(ds, dim, cam, cfg)
+
+    def step():
+        return rdist.render_frame(local_fn, WIDTH, HEIGHT, TILE_ROWS, device)
+
+    for _ in range(args.warmup):
+        step()
+    stage_ms = {"pass1": 0.0, "aa": 0.0, "encode": 0.0}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded by the library on the launch stream; reading them waits for this frame only
+        tm = ds.last_timings()
+        for k in stage_ms:
+            stage_ms[k] += tm[k]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed = float(et.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        for k in stage_ms:
+            stage_ms[k] /= args.steps
+        # dominant kernel of rank 0's share
+        if stage_ms["aa"] >= stage_ms["pass1"]:
+            kernel, k_ms, k_flops = "k_aa_resolve", stage_ms["aa"], flops_aa
+        else:
+            kernel, k_ms, k_flops = "k_pass1", stage_ms["pass1"], flops_pass1
+        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        fb_bytes = WIDTH * HEIGHT * (32 + 3)   # f64 colour+distance written once, RGB8 written once
+        out = {
+            "metric": "Mrays/s, glass_monkey 1920x1080 AA on (ms/frame in ms_per_step)",
+            "value": rays_total / (elapsed / args.steps) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "glass_monkey 1920x1080, anti_alias on, aa_rays 5, recursion_depth 20, seed 1",
+                       "rays_per_frame": int(rays_total), "tile_rows": TILE_ROWS,
+                       "parallelism": f"row-block interleave x{world}, RGB8 gather to rank 0"},
+            "stage_ms_rank0": stage_ms,
+            "roofline": {"bound": "valu_fp64", "kernel": kernel, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": int(k_flops), "avg_launch_ms": k_ms,
+                         "hbm_secondary": {"achieved": fb_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, dim, cam, cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def scenes_mod():
+    return importlib.import_module("rust-raytracer_amd.scenes")
+
+
+@pytest.fixture(scope="session")
+def render_mod():
+    return importlib.import_module("rust-raytracer_amd.render")
+
+
+@pytest.fixture(scope="session")
+def abi_mod():
+    return importlib.import_module("rust-raytracer_amd._abi")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    return binding
+
+
+@pytest.fixture(scope="session")
+def scene_cache(scenes_mod):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = scenes_mod.Scene(name)
+        return cache[name]
+    return get
