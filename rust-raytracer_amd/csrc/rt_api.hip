@@ -61,6 +61,7 @@ struct RtScene {
     DScene ds{};
     std::vector<void*> owned;
     uint32_t max_spawn = 0;
+    uint32_t lds_limit = 65536;
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
@@ -129,6 +130,20 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     d.num_lights = (uint32_t)fs.lights.size();
     std::memcpy(d.ambient, fs.ambient, sizeof d.ambient);
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
+    d.features = fs.features; d.max_ray_spawn = fs.max_ray_spawn; d.max_shadow_spawn = fs.max_shadow_spawn;
+    d.inline_point_lights = fs.inline_point_lights;
+    {   // LDS-resident BVH when every mesh fits beside nothing else in one CU's LDS
+        while (fs.lds_blob.size() % 16) fs.lds_blob.push_back(0);
+        int lds_max = 0;
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+        s->lds_limit = lds_max > 0 ? (uint32_t)lds_max : 65536u;
+        d.lds_blob = nullptr; d.lds_blob_bytes = 0;
+        if ((fs.features & RTF_MESH) && !fs.lds_blob.empty() && fs.lds_blob.size() <= s->lds_limit) {
+            rc = upload(fs.lds_blob, s->owned, &d.lds_blob);
+            if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+            d.lds_blob_bytes = (uint32_t)fs.lds_blob.size();
+        }
+    }
     for (auto& e : s->ev)
         if (hipEventCreate(&e) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
     *out = s;
@@ -145,6 +160,39 @@ uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_
 }  // extern "C"
 
 namespace {
+
+// The trace kernel is compiled for a few feature sets; a scene runs on the smallest one that
+// covers what it contains (fewer registers and less scratch than the all-features build).
+template <uint32_t F>
+int launch_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
+    uint32_t block = 64, lds = 0;
+    if (F & RTF_LDS_BVH) {   // one 512-thread workgroup per CU, the BVH blob in its LDS
+        block = 512; lds = ds.lds_blob_bytes;
+        grid = std::max(1u, grid / 16);
+        auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea));
+    }
+    if (count) hipLaunchKernelGGL((k_trace<F, true>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
+    else hipLaunchKernelGGL((k_trace<F, false>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("k_trace launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+constexpr uint32_t V_MESH = RTF_MESH;                                         // rooms + meshes, point lights (glass_monkey)
+constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
+constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES;                           // one-way spheres, skybox, maps (many_balls)
+constexpr uint32_t V_CSG = RTF_CSG | RTF_FACED | RTF_IMAGES;                  // composite shapes under a skybox
+int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
+    auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
+    if (covers(0u)) return launch_variant<0u>(count, grid, stream, ds, rp, ta);
+    if (covers(V_MESH) && ds.lds_blob_bytes) return launch_variant<V_MESH | RTF_LDS_BVH>(count, grid, stream, ds, rp, ta);
+    if (covers(V_MESH)) return launch_variant<V_MESH>(count, grid, stream, ds, rp, ta);
+    if (covers(V_BALLS)) return launch_variant<V_BALLS>(count, grid, stream, ds, rp, ta);
+    if (covers(V_AREA)) return launch_variant<V_AREA>(count, grid, stream, ds, rp, ta);
+    if (covers(V_CSG)) return launch_variant<V_CSG>(count, grid, stream, ds, rp, ta);
+    return launch_variant<RTF_ALL>(count, grid, stream, ds, rp, ta);
+}
 
 int check_args(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg) {
     if (!scene || !dim || !cam || !cfg) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
@@ -225,15 +273,19 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
     const uint32_t max_waves = (uint32_t)s->num_cus * 16;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
+    // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
+    {
+        uint64_t need = (uint64_t)(s->ds.max_ray_spawn > 0 ? s->ds.max_ray_spawn - 1 : 0) * rc.recursion_depth + 1 + s->ds.max_shadow_spawn + s->ds.max_ray_spawn;
+        if (need > RT_MAX_STACK) return fail(RT_ERR_CAPACITY, "rt_render: recursion_depth x rays-per-hit exceeds the device ray stack");
+    }
+    TraceArgs ta{};
+    ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
+    ta.color = (double*)s->color.p; ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
+    ta.list = nullptr; ta.count = aa_count; ta.samples = nullptr; ta.next_item = next_tile; ta.counters = counters; ta.mode = 0;
     if (num_rows > 0) {
         uint32_t grid = std::min(tiles, max_waves);
-        if (count_work)
-            hipLaunchKernelGGL(k_pass1<true>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->rows.p, num_rows,
-                               (double*)s->color.p, (double*)s->distance.p, (uint32_t*)s->hit_id.p, next_tile, counters);
-        else
-            hipLaunchKernelGGL(k_pass1<false>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->rows.p, num_rows,
-                               (double*)s->color.p, (double*)s->distance.p, (uint32_t*)s->hit_id.p, next_tile, counters);
-        HIP_TRY(hipGetLastError());
+        int lrc = launch_trace(s->ds.features, count_work, grid, stream, s->ds, rp, ta);
+        if (lrc != RT_OK) return lrc;
     }
     HIP_TRY(hipEventRecord(s->ev[1], stream));
     if (rc.anti_alias && W >= 3 && H >= 3 && num_rows > 0) {
@@ -245,14 +297,9 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, (const double*)s->distance.p,
                            (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
         HIP_TRY(hipGetLastError());
-        uint32_t grid = max_waves;
-        if (count_work)
-            hipLaunchKernelGGL(k_aa_resolve<true>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->list.p, aa_count,
-                               (double*)s->samples.p, next_chunk, counters);
-        else
-            hipLaunchKernelGGL(k_aa_resolve<false>, dim3(grid), dim3(64), 0, stream, s->ds, rp, (const uint32_t*)s->list.p, aa_count,
-                               (double*)s->samples.p, next_chunk, counters);
-        HIP_TRY(hipGetLastError());
+        ta.list = (const uint32_t*)s->list.p; ta.samples = (double*)s->samples.p; ta.next_item = next_chunk; ta.mode = 1;
+        int lrc = launch_trace(s->ds.features, count_work, max_waves, stream, s->ds, rp, ta);
+        if (lrc != RT_OK) return lrc;
         hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
                            (const double*)s->samples.p, (double*)s->color.p, (double*)s->distance.p);
         HIP_TRY(hipGetLastError());

@@ -20,7 +20,19 @@
 #define RT_CSG_ARENA 96        // hits across all live lists of one composite query
 #define RT_CSG_MAX_LISTS 12
 #define RT_SHADE_MAX_FRAMES 8  // nesting depth of group shaders
-#define RT_SHADE_MAX_SPAWN 8   // secondary rays one hit may spawn
+#define RT_SHADE_MAX_SPAWN 16  // secondary + deferred shadow rays one hit may spawn
+
+// Scene features: the trace kernels are compiled for a handful of feature sets so that a
+// scene only pays (registers, scratch, code) for what it contains.
+#define RTF_MESH 1u            // triangle meshes
+#define RTF_CSG 2u             // composite shapes
+#define RTF_FACED 4u           // Cube / Tetrahedron
+#define RTF_MISC 8u            // Plane, Triangle, Polygon, Polyhedron
+#define RTF_WRAP 16u           // OneWay / Inverted
+#define RTF_INLINE_LIGHTS 32u  // lights whose shadow tests cannot be deferred (square, directional, Phong under a ray-spawning Mix)
+#define RTF_IMAGES 64u         // textures, normal / bump maps, skybox
+#define RTF_ALL 127u
+#define RTF_LDS_BVH 128u        // kernel variant: mesh BVHs are walked out of LDS (512-thread workgroups, one per CU)
 
 struct DAffine {               // y = R x + t, rows of R in r[0..3), r[4..7), r[8..11) with t at r[3], r[7], r[11]
     double r[12];
@@ -65,8 +77,8 @@ struct DFaced {                // Cube (6 rectangles) / Tetrahedron (4 triangles
 
 struct DBvhNode {              // binary BVH; both children's boxes are stored in the parent
     double lo[2][3], hi[2][3];
-    uint32_t child[2];         // bit 31 set: leaf, low bits = first triangle; else node index
-    uint32_t count[2];         // leaf: triangle count
+    uint32_t child[2];         // bit 31: leaf, bits 28..30: triangle count, low 28 bits: first triangle; else node index
+    uint32_t count[2];         // leaf: triangle count (host-side bookkeeping)
 };
 
 struct DMeshTri {              // one mesh face in BVH order (mesh.rs:416-466 inputs)
@@ -75,8 +87,22 @@ struct DMeshTri {              // one mesh face in BVH order (mesh.rs:416-466 in
     uint32_t i1, i2, i3, face;
 };
 
+// Copies of the BVH for the LDS-resident walk: boxes rounded outward to f32 (they only cull;
+// every arithmetic step still runs in f64), triangles without their attribute indices.
+struct LBvhNode {              // 64 bytes
+    float lo[2][3], hi[2][3];
+    uint32_t child[2];         // bit 31: leaf, bits 28..30: triangle count, low bits: first triangle; else node index
+    uint32_t _pad[2];
+};
+struct LMeshTri {              // 112 bytes
+    double v1[3], v2[3], v3[3], n[3];
+    double inv_area;
+    double _pad;
+};
+
 struct DMesh {
     uint32_t node_off, tri_off, num_tris, num_nodes;
+    uint32_t lds_node_off, lds_tri_off;   // byte offsets into the scene's LDS blob
     uint32_t normal_off, uv_off;   // into mesh_normals (3/vertex) and mesh_uvs (2/vertex)
     uint32_t num_normals, num_uvs;
     double lo[3], hi[3];
@@ -139,6 +165,12 @@ struct DScene {
     double ambient[3];           // ambient colour * power
     uint32_t has_background, background_image;
     DAffine background_w2l;
+    const uint8_t* lds_blob;     // LBvhNode / LMeshTri arrays of every mesh, staged into LDS by each workgroup
+    uint32_t lds_blob_bytes;     // 0: the meshes do not fit; walk the global-memory BVH instead
+    uint32_t features;           // RTF_* bits this scene needs
+    uint32_t max_ray_spawn;      // most secondary rays one hit can push
+    uint32_t max_shadow_spawn;   // most deferred shadow tests one hit can push
+    uint32_t inline_point_lights; // 1: point-light shadow tests run inside Phong (needs RTF_INLINE_LIGHTS)
 };
 
 struct DCamera {

@@ -135,6 +135,8 @@ struct FlatScene {
     uint32_t has_background = 0, background_image = 0;
     DAffine background_w2l{};
     uint32_t max_mesh_bvh_bytes = 0;
+    uint32_t features = 0, max_ray_spawn = 0, max_shadow_spawn = 0, inline_point_lights = 0;
+    std::vector<uint8_t> lds_blob;   // LBvhNode + LMeshTri arrays of all meshes
 };
 
 // ---- BVH build: binned SAH, leaves of <= 4 triangles ----
@@ -211,6 +213,7 @@ inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes
 
 inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& m) {
     if (m.num_faces == 0) throw Invalid("mesh without faces");
+    if (m.num_faces >= (1u << 28)) throw Unsupported("mesh with 2^28 or more faces");
     const double* P = d.mesh_f64 + m.positions_off;
     const uint32_t* F = d.mesh_u32 + m.faces_off;
     auto pos = [&](uint32_t i) { if (i >= m.num_positions) throw Invalid("mesh face index out of range"); return V3{P[3 * i], P[3 * i + 1], P[3 * i + 2]}; };
@@ -250,7 +253,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     for (size_t i = 0; i < bn.size(); ++i) if (bn[i].left >= 0) { interior_index[i] = (int)order.size(); order.push_back((int)i); }
     auto child_ref = [&](int b, uint32_t& ref, uint32_t& cnt) {
         if (bn[b].left >= 0) { ref = (uint32_t)interior_index[b]; cnt = 0; }
-        else { ref = 0x80000000u | bn[b].first; cnt = bn[b].count; }
+        else { ref = 0x80000000u | (bn[b].count << 28) | bn[b].first; cnt = bn[b].count; }
     };
     auto set_box = [&](DBvhNode& n, int k, const BuildNode& b) {
         n.lo[k][0] = b.lo.x - pad; n.lo[k][1] = b.lo.y - pad; n.lo[k][2] = b.lo.z - pad;
@@ -259,7 +262,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     if (order.empty()) {
         DBvhNode n{};
         set_box(n, 0, bn[0]);
-        n.child[0] = 0x80000000u | bn[0].first; n.count[0] = bn[0].count;
+        n.child[0] = 0x80000000u | (bn[0].count << 28) | bn[0].first; n.count[0] = bn[0].count;
         const double inf = std::numeric_limits<double>::infinity();
         for (int k = 0; k < 3; ++k) { n.lo[1][k] = inf; n.hi[1][k] = -inf; }
         n.child[1] = 0x80000000u; n.count[1] = 0;
@@ -280,6 +283,32 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     dm.uv_off = (uint32_t)(fs.mesh_uvs.size() / 2);
     dm.num_uvs = m.num_texcoords;
     fs.mesh_uvs.insert(fs.mesh_uvs.end(), d.mesh_f64 + m.texcoords_off, d.mesh_f64 + m.texcoords_off + 2 * (size_t)m.num_texcoords);
+    // LDS copies: f32 boxes rounded outward, triangles without indices
+    {
+        auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
+        auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
+        while (fs.lds_blob.size() % 16) fs.lds_blob.push_back(0);
+        dm.lds_node_off = (uint32_t)fs.lds_blob.size();
+        for (uint32_t i = 0; i < dm.num_nodes; ++i) {
+            const DBvhNode& n = fs.bvh_nodes[dm.node_off + i];
+            LBvhNode l{};
+            for (int c = 0; c < 2; ++c) {
+                for (int k = 0; k < 3; ++k) { l.lo[c][k] = down(n.lo[c][k]); l.hi[c][k] = up(n.hi[c][k]); }
+                l.child[c] = n.child[c];
+            }
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(&l);
+            fs.lds_blob.insert(fs.lds_blob.end(), b, b + sizeof l);
+        }
+        dm.lds_tri_off = (uint32_t)fs.lds_blob.size();
+        for (uint32_t i = 0; i < dm.num_tris; ++i) {
+            const DMeshTri& t = fs.mesh_tris[dm.tri_off + i];
+            LMeshTri l{};
+            std::memcpy(l.v1, t.v1, sizeof l.v1); std::memcpy(l.v2, t.v2, sizeof l.v2); std::memcpy(l.v3, t.v3, sizeof l.v3);
+            std::memcpy(l.n, t.n, sizeof l.n); l.inv_area = t.inv_area;
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(&l);
+            fs.lds_blob.insert(fs.lds_blob.end(), b, b + sizeof l);
+        }
+    }
     fs.meshes.push_back(dm);
     uint32_t bytes = dm.num_nodes * (uint32_t)sizeof(DBvhNode) + dm.num_tris * (uint32_t)sizeof(DMeshTri);
     fs.max_mesh_bvh_bytes = std::max(fs.max_mesh_bvh_bytes, bytes);
@@ -331,12 +360,78 @@ public:
         }
         // instances: DFS pre-order with composed transforms
         walk(0, identity(), identity());
+        analyse();
     }
 
 private:
     const RtSceneDesc& d_;
     FlatScene& fs_;
     std::vector<uint32_t> prim_map_, mesh_map_;
+
+    // Which kernel features the scene needs and how many rays one hit can push.
+    uint32_t point_lights_ = 0;
+    bool mix_needs_inline(uint32_t i) {   // a Mix whose product has two factors that depend on traced rays
+        const RtShader& s = d_.shaders[i];
+        bool need = false;
+        if (s.kind == RT_SHADER_MIX) {
+            int pending = 0;
+            for (uint32_t k = 0; k < s.num_children; ++k) {
+                uint32_t c = d_.shader_child_idx[s.first_child + k];
+                if (spawns(c, 0) || has_phong(c)) ++pending;
+            }
+            need = pending > 1;
+        }
+        if (s.kind == RT_SHADER_MIX || s.kind == RT_SHADER_COMPOSITE || s.kind == RT_SHADER_CHAIN)
+            for (uint32_t k = 0; k < s.num_children; ++k) need |= mix_needs_inline(d_.shader_child_idx[s.first_child + k]);
+        return need;
+    }
+    bool has_phong(uint32_t i) {
+        const RtShader& s = d_.shaders[i];
+        if (s.kind == RT_SHADER_PHONG) return point_lights_ > 0;
+        if (s.kind == RT_SHADER_MIX || s.kind == RT_SHADER_COMPOSITE) {
+            for (uint32_t k = 0; k < s.num_children; ++k) if (has_phong(d_.shader_child_idx[s.first_child + k])) return true;
+            return false;
+        }
+        if (s.kind == RT_SHADER_CHAIN) return has_phong(d_.shader_child_idx[s.first_child + s.num_children - 1]);
+        return false;
+    }
+    uint32_t count_phongs(uint32_t i) {
+        const RtShader& s = d_.shaders[i];
+        if (s.kind == RT_SHADER_PHONG) return 1;
+        if (s.kind == RT_SHADER_MIX || s.kind == RT_SHADER_COMPOSITE) {
+            uint32_t n = 0;
+            for (uint32_t k = 0; k < s.num_children; ++k) n += count_phongs(d_.shader_child_idx[s.first_child + k]);
+            return n;
+        }
+        if (s.kind == RT_SHADER_CHAIN) return count_phongs(d_.shader_child_idx[s.first_child + s.num_children - 1]);
+        return 0;
+    }
+    void analyse() {
+        uint32_t f = 0;
+        for (const DPrim& p : fs_.prims) {
+            switch (p.kind) {
+                case DP_MESH: f |= RTF_MESH; break;
+                case DP_CSG: f |= RTF_CSG; break;
+                case DP_FACED: f |= RTF_FACED; break;
+                case DP_PLANE: case DP_TRIANGLE: case DP_POLYGON: case DP_POLYHEDRON: f |= RTF_MISC; break;
+                default: break;
+            }
+            if (p.wrap) f |= RTF_WRAP;
+        }
+        if (!fs_.images.empty()) f |= RTF_IMAGES;
+        point_lights_ = 0;
+        for (const DLight& l : fs_.lights) { if (l.kind == RT_LIGHT_POINT) ++point_lights_; else f |= RTF_INLINE_LIGHTS; }
+        bool inline_points = false;
+        uint32_t max_r = 0, max_s = 0;
+        for (const DInstance& in : fs_.instances) {
+            if (mix_needs_inline(in.shader)) inline_points = true;
+            uint32_t r = count_spawns(in.shader), s = count_phongs(in.shader) * point_lights_;
+            max_r = std::max(max_r, r); max_s = std::max(max_s, s);
+        }
+        if (max_r + max_s > RT_SHADE_MAX_SPAWN) inline_points = true;
+        if (inline_points) { f |= RTF_INLINE_LIGHTS; max_s = 0; }
+        fs_.features = f; fs_.max_ray_spawn = max_r; fs_.max_shadow_spawn = max_s; fs_.inline_point_lights = inline_points ? 1 : 0;
+    }
 
     void walk(uint32_t i, const Mat4& parent_l2w, const Mat4& parent_w2l) {
         if (i >= d_.num_nodes) throw Invalid("node index out of range");
@@ -584,7 +679,7 @@ private:
                 o.nm_count = (uint32_t)fs_.chain_nmaps.size() - o.nm_begin;
             }
             spawns(i, 0);
-            if (count_spawns(i) > RT_SHADE_MAX_SPAWN) throw Unsupported("shader spawns more secondary rays per hit than the device path buffers");
+            if (count_spawns(i) > RT_SHADE_MAX_SPAWN / 2) throw Unsupported("shader spawns more secondary rays per hit than the device path buffers");
             fs_.shaders.push_back(o);
         }
         fs_.shader_child_idx.assign(d_.shader_child_idx, d_.shader_child_idx + d_.num_shader_children);

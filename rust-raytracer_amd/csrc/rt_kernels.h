@@ -1,74 +1,29 @@
-// rt_kernels.h — the kernels of the render path: pass 1 over all pixels, anti-alias
-// detect / resolve / combine, and the clamp-gamma-encode stage.
+// rt_kernels.h — the kernels of the render path: the trace kernel (pass 1 and the
+// anti-alias resolve), AA detect / combine, and the clamp-gamma-encode stage.
 //
 // Frame driver they replace: render_with_config (src/render.rs:99-312) with its
-// thread pool (src/multithread.rs).  Work is handed out dynamically: every wave of
-// a fixed-size grid pulls 8x8-pixel tiles (pass 1) or 64-sample chunks (AA) from a
-// global counter until none are left, which balances the very uneven cost of glass
-// pixels against wall pixels the way the reference's 500 row-chunks do for CPU threads.
+// thread pool (src/multithread.rs).
+//
+// k_trace is a persistent kernel.  Every lane owns one camera sample at a time and a
+// private stack of pending rays; each trip round the main loop pops ONE entry and runs
+// ONE scene query for it — closest hit for camera / reflected / refracted rays, any-hit
+// for the deferred point-light shadow tests — so all 64 lanes of a wave sit in the same
+// traversal code whatever kind of ray they carry.  A lane whose stack runs empty writes
+// its sample and immediately takes the next one from the wave's chunk of the global work
+// counter: cheap wall pixels (4 rays) and expensive glass pixels (hundreds) no longer
+// wait for each other inside a wave, which is what the reference's 500 dynamic row-chunks
+// achieve for CPU threads.
 #pragma once
 #include "rt_shade.h"
 
-struct StackRay {         // one pending secondary ray (Ray of src/geometry/ray.rs:4-9 plus its pixel weight)
+struct StackRay {         // one pending ray (Ray of src/geometry/ray.rs:4-9 plus its pixel weight)
     d3 o, d;
-    d3 w;                 // product of the shader weights from the camera to this ray
-    d3 c;                 // Ray::contribution
-    uint32_t depth, path;
+    d3 w;                 // RAY: product of shader weights from the camera to this ray; SHADOW: colour added if the light is visible
+    d3 c;                 // RAY: Ray::contribution; SHADOW: c.x = distance to the light
+    uint32_t depth;       // RAY: remaining depth; SHADOW: 0xFFFFFFFF
+    uint32_t path;
 };
-
-struct SampleResult {
-    d3 color;
-    double distance;
-    uint32_t hit_id;
-};
-
-// Scene::cast_ray_get_distance for one camera sample, with the recursion of
-// reflect / refract turned into an explicit stack (src/scene.rs:66-85 + shader/*.rs).
-template <bool COUNT>
-RT_DEV SampleResult trace_sample(const DScene& sc, d3 origin, d3 dir, uint32_t max_depth, uint64_t stream,
-                                 Work<COUNT>& wk, unsigned long long& camera_rays) {
-    StackRay stack[RT_MAX_STACK];
-    int sp = 0;
-    stack[0].o = origin; stack[0].d = dir;
-    stack[0].w = mk3(1.0, 1.0, 1.0); stack[0].c = mk3(1.0, 1.0, 1.0);
-    stack[0].depth = max_depth; stack[0].path = 1u;
-    sp = 1;
-    SampleResult res;
-    res.color = mk3(0.0, 0.0, 0.0); res.distance = INFINITY; res.hit_id = 0xFFFFFFFFu;
-    bool primary = true;
-    while (sp > 0) {
-        StackRay r = stack[--sp];
-        bool is_primary = primary;
-        primary = false;
-        // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
-        if (!(r.depth > 0 && (r.c.x + r.c.y + r.c.z) > RT_MIN_CONTRIBUTION)) {
-            res.color = res.color + r.w * background_color(sc, r.d);
-            continue;
-        }
-        if (COUNT) { if (is_primary) camera_rays++; else wk.rays_secondary++; }
-        SceneHit h;
-        if (!trace_closest<COUNT>(sc, r.o, r.d, h, wk)) {
-            res.color = res.color + r.w * background_color(sc, r.d);
-            continue;
-        }
-        WorldHit wh;
-        world_hit<COUNT>(sc, r.o, r.d, h, wh, wk);
-        const DInstance& in = sc.instances[h.inst];
-        if (is_primary) { res.distance = h.t; res.hit_id = in.node_id; }
-        Spawn spawn[RT_SHADE_MAX_SPAWN];
-        uint32_t nspawn;
-        d3 local = shade_hit<COUNT>(sc, in.shader, wh, r.d, r.c, stream, r.path, spawn, nspawn, wk);
-        res.color = res.color + r.w * local;
-        for (uint32_t i = nspawn; i-- > 0;) {
-            if (sp >= RT_MAX_STACK) { RT_COUNT(wk, stack_overflows); continue; }
-            StackRay& s = stack[sp++];
-            s.o = spawn[i].o; s.d = spawn[i].d;
-            s.w = r.w * spawn[i].w; s.c = spawn[i].c;
-            s.depth = r.depth - 1; s.path = child_path(r.path, spawn[i].ordinal);
-        }
-    }
-    return res;
-}
+#define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
 // calculate_pixel_location + Ray::from_destination (src/render.rs:127-132,167-168).
 // (px, py) already include the caller's +0.5; the closure adds another 0.5.
@@ -97,36 +52,179 @@ RT_DEV void flush_counters(DCounters* g, const Work<COUNT>& wk, unsigned long lo
     atomicAdd(&g->stack_overflows, wk.stack_overflows);
 }
 
-// ------------------------------------------------------------------ pass 1 (src/render.rs:152-181)
-// rows[] lists the image rows this rank renders (its own row blocks plus the one-row
-// halo the AA stencil needs); tiles are 8x8 pixels over (width x num_rows).
-template <bool COUNT>
-__global__ void __launch_bounds__(64)
-k_pass1(DScene sc, DRenderParams rp, const uint32_t* __restrict__ rows, uint32_t num_rows,
-        double* __restrict__ color, double* __restrict__ distance, uint32_t* __restrict__ hit_id,
-        unsigned int* __restrict__ next_tile, DCounters* __restrict__ counters) {
+struct TraceArgs {
+    // pass 1 (mode 0): rows[] lists the image rows this rank renders (its own row blocks plus the
+    // one-row halo the AA stencil needs); work items are pixels in 8x8 tiles over (width x num_rows)
+    const uint32_t* rows;
+    uint32_t num_rows;
+    double* color;            // W*H*3
+    double* distance;         // W*H
+    uint32_t* hit_id;         // W*H
+    // AA resolve (mode 1): one work item per (flagged pixel, extra ray), src/render.rs:259-299
+    const uint32_t* list;
+    const unsigned int* count;
+    double* samples;          // count*aa_rays*3
+    unsigned int* next_item;  // global work counter
+    DCounters* counters;
+    uint32_t mode;
+};
+
+template <uint32_t F, bool COUNT>
+__global__ void __launch_bounds__((F & RTF_LDS_BVH) ? 512 : 64)
+k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
+    if constexpr (F & RTF_LDS_BVH) {
+        // stage every mesh's BVH nodes and triangles into LDS once per workgroup
+        const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);
+        uint4* dst = reinterpret_cast<uint4*>(rt_lds_dynamic);
+        for (uint32_t i = threadIdx.x; i < sc.lds_blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t W = rp.cam.width;
-    const uint32_t tiles_x = (W + 7) / 8, tiles_y = (num_rows + 7) / 8;
-    const uint32_t total = tiles_x * tiles_y;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles_x = (W + 7) / 8;
+    uint32_t total;
+    if (a.mode == 0) total = tiles_x * ((a.num_rows + 7) / 8) * 64;
+    else total = *a.count * rp.aa_rays;
+    const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
+    const d3 cam_o = ld3(rp.cam.origin);
+
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
+    StackRay stack[RT_MAX_STACK];
+    int sp = 0;
+    // the sample this lane is working on
+    bool active = false, exhausted = false, first = true;
+    uint32_t item = 0;
+    size_t out_index = 0;
+    uint64_t stream = 0;
+    d3 color = mk3(0.0, 0.0, 0.0);
+    double distance = INFINITY;
+    uint32_t hit_id = 0xFFFFFFFFu;
+    // the wave's reserved chunk of the work counter (wave-uniform)
+    uint32_t chunk_next = 0, chunk_end = 0;
+
     for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(next_tile, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= total) break;
-        uint32_t x = (tile % tiles_x) * 8 + (lane & 7), ry = (tile / tiles_x) * 8 + (lane >> 3);
-        if (x >= W || ry >= num_rows) continue;
-        uint32_t y = rows[ry];
-        size_t pixel = (size_t)y * W + x;
-        d3 dir = camera_dir(rp.cam, (double)x + 0.5, (double)y + 0.5);
-        SampleResult r = trace_sample<COUNT>(sc, ld3(rp.cam.origin), dir, rp.recursion_depth, rng_stream(rp.seed, pixel, 0), wk, cam);
-        color[3 * pixel] = r.color.x; color[3 * pixel + 1] = r.color.y; color[3 * pixel + 2] = r.color.z;
-        distance[pixel] = r.distance;
-        hit_id[pixel] = r.hit_id;
+        // ---------------- finish / refill
+        if (active && sp == 0) {
+            if (a.mode == 0) {
+                a.color[3 * out_index] = color.x; a.color[3 * out_index + 1] = color.y; a.color[3 * out_index + 2] = color.z;
+                a.distance[out_index] = distance;
+                a.hit_id[out_index] = hit_id;
+            } else {
+                a.samples[3 * out_index] = color.x; a.samples[3 * out_index + 1] = color.y; a.samples[3 * out_index + 2] = color.z;
+            }
+            active = false;
+        }
+        bool need = !active && !exhausted;
+        unsigned long long needy = __ballot(need);
+        if (needy) {
+            uint32_t want = (uint32_t)__popcll(needy);
+            uint32_t rank = (uint32_t)__popcll(needy & ((1ull << lane) - 1ull));
+            uint32_t avail = chunk_end - chunk_next;
+            if (avail < want) {
+                // hand out the remainder, then reserve a new chunk for the rest
+                uint32_t base = 0;
+                if (lane == (uint32_t)(__ffsll((long long)needy) - 1)) base = atomicAdd(a.next_item, 64u);
+                base = __shfl(base, __ffsll((long long)needy) - 1);
+                if (need) item = rank < avail ? chunk_next + rank : base + (rank - avail);
+                chunk_next = base + (want - avail);
+                chunk_end = base + 64u;
+            } else {
+                if (need) item = chunk_next + rank;
+                chunk_next += want;
+            }
+            if (need) {
+                if (item >= total) {
+                    exhausted = true;
+                } else {
+                    // ---- set up the camera sample
+                    d3 dir;
+                    bool valid = true;
+                    if (a.mode == 0) {
+                        uint32_t tile = item >> 6, within = item & 63u;
+                        uint32_t x = (tile % tiles_x) * 8 + (within & 7u), ry = (tile / tiles_x) * 8 + (within >> 3);
+                        if (x >= W || ry >= a.num_rows) valid = false;
+                        else {
+                            uint32_t y = a.rows[ry];
+                            out_index = (size_t)y * W + x;
+                            dir = camera_dir(rp.cam, (double)x + 0.5, (double)y + 0.5);      // render.rs:167
+                            stream = rng_stream(rp.seed, out_index, 0);
+                        }
+                    } else {
+                        uint32_t f = item / rp.aa_rays, i = item % rp.aa_rays;
+                        uint32_t pixel = a.list[f];
+                        uint32_t x = pixel % W, y = pixel / W;
+                        uint64_t stream0 = rng_stream(rp.seed, pixel, 0);
+                        double rand_rotation = 0.0 + (2.0 * RT_PI - 0.0) * rng_aa(stream0, 0);   // render.rs:266
+                        double ax = cos(rand_rotation + theta * (double)i);
+                        double ay = sin(rand_rotation + theta * (double)i);
+                        double rand_distance = 0.2 + (0.5 - 0.2) * rng_aa(stream0, 1 + i);       // render.rs:277
+                        dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
+                        stream = rng_stream(rp.seed, pixel, 1 + i);
+                        out_index = item;
+                    }
+                    if (valid) {
+                        active = true; first = true;
+                        color = mk3(0.0, 0.0, 0.0); distance = INFINITY; hit_id = 0xFFFFFFFFu;
+                        stack[0].o = cam_o; stack[0].d = dir;
+                        stack[0].w = mk3(1.0, 1.0, 1.0); stack[0].c = mk3(1.0, 1.0, 1.0);
+                        stack[0].depth = rp.recursion_depth; stack[0].path = 1u;
+                        sp = 1;
+                    }
+                }
+            }
+        }
+        if (__ballot(active || !exhausted) == 0ull) break;
+        if (!active) continue;
+
+        // ---------------- one ray
+        StackRay r = stack[--sp];
+        const bool shadow = r.depth == RT_SHADOW_ENTRY;
+        if (!shadow) {
+            // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
+            if (!(r.depth > 0 && (r.c.x + r.c.y + r.c.z) > RT_MIN_CONTRIBUTION)) {
+                color = color + r.w * background_color<F>(sc, r.d);
+                first = false;
+                continue;
+            }
+            if (COUNT) { if (first) cam++; else wk.rays_secondary++; }
+        } else {
+            RT_COUNT(wk, rays_shadow);
+        }
+        SceneHit h;
+        bool found = trace_scene<F, COUNT>(sc, r.o, r.d, shadow, r.c.x, h, wk);
+        if (shadow) {
+            if (!found) { color = color + r.w; RT_COUNT(wk, shade_evals); }
+            continue;
+        }
+        const bool is_primary = first;
+        first = false;
+        if (!found) {
+            color = color + r.w * background_color<F>(sc, r.d);
+            continue;
+        }
+        WorldHit wh;
+        world_hit<F, COUNT>(sc, r.o, r.d, h, wh, wk);
+        const DInstance& in = sc.instances[h.inst];
+        if (is_primary) { distance = h.t; hit_id = in.node_id; }
+        Spawn spawn[RT_SHADE_MAX_SPAWN];
+        uint32_t nspawn;
+        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, r.d, r.c, stream, r.path, spawn, nspawn, wk);
+        color = color + r.w * local;
+        // secondary rays first, shadow tests on top so that they are resolved next
+        for (int pass = 0; pass < 2; ++pass)
+            for (uint32_t i = nspawn; i-- > 0;) {
+                if ((spawn[i].shadow != 0) != (pass == 1)) continue;
+                if (sp >= RT_MAX_STACK) { RT_COUNT(wk, stack_overflows); continue; }
+                StackRay& s = stack[sp++];
+                s.o = spawn[i].o; s.d = spawn[i].d;
+                s.w = r.w * spawn[i].w; s.c = spawn[i].c;
+                if (spawn[i].shadow) { s.depth = RT_SHADOW_ENTRY; s.path = 0; }
+                else { s.depth = r.depth - 1; s.path = child_path(r.path, spawn[i].ordinal); }
+            }
     }
-    flush_counters<COUNT>(counters, wk, cam, 0);
+    if (a.mode == 0) flush_counters<COUNT>(a.counters, wk, cam, 0);
+    else flush_counters<COUNT>(a.counters, wk, 0, cam);
 }
 
 // ------------------------------------------------------------------ AA detect (src/render.rs:202-220)
@@ -164,42 +262,6 @@ k_aa_detect(DRenderParams rp, const double* __restrict__ color, const double* __
         base = __shfl(base, leader);
         if (flag) { list[base + rank] = y * W + x; mask[(size_t)y * W + x] = 1; }
     }
-}
-
-// ------------------------------------------------------------------ AA resolve (src/render.rs:259-299)
-// One work item per (flagged pixel, extra ray).
-template <bool COUNT>
-__global__ void __launch_bounds__(64)
-k_aa_resolve(DScene sc, DRenderParams rp, const uint32_t* __restrict__ list, const unsigned int* __restrict__ count,
-             double* __restrict__ samples, unsigned int* __restrict__ next_chunk, DCounters* __restrict__ counters) {
-    const uint32_t total = *count * rp.aa_rays;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t W = rp.cam.width;
-    const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // :227
-    Work<COUNT> wk = {};
-    unsigned long long cam = 0;
-    for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(next_chunk, 1u);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        if ((unsigned long long)chunk * 64ull >= total) break;
-        uint32_t item = chunk * 64 + lane;
-        if (item >= total) continue;
-        uint32_t f = item / rp.aa_rays, i = item % rp.aa_rays;
-        uint32_t pixel = list[f];
-        uint32_t x = pixel % W, y = pixel / W;
-        uint64_t stream0 = rng_stream(rp.seed, pixel, 0);
-        double rand_rotation = 0.0 + (2.0 * RT_PI - 0.0) * rng_aa(stream0, 0);      // :266
-        double ax = cos(rand_rotation + theta * (double)i);
-        double ay = sin(rand_rotation + theta * (double)i);
-        double rand_distance = 0.2 + (0.5 - 0.2) * rng_aa(stream0, 1 + i);          // :277
-        double x_pos = (double)x + 0.5 + ax * rand_distance;
-        double y_pos = (double)y + 0.5 + ay * rand_distance;
-        d3 dir = camera_dir(rp.cam, x_pos, y_pos);
-        SampleResult r = trace_sample<COUNT>(sc, ld3(rp.cam.origin), dir, rp.recursion_depth, rng_stream(rp.seed, pixel, 1 + i), wk, cam);
-        samples[3 * (size_t)item] = r.color.x; samples[3 * (size_t)item + 1] = r.color.y; samples[3 * (size_t)item + 2] = r.color.z;
-    }
-    flush_counters<COUNT>(counters, wk, 0, cam);
 }
 
 // mean of the original sample and the extra ones, distance := 0 (src/render.rs:291-297, 306)

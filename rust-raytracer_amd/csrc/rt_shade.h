@@ -11,14 +11,21 @@
 // the rays on its stack; no recursion is needed because every group shader is linear
 // in the colours of the rays below it (MixShader with two ray-spawning factors is the
 // one non-linear case and is refused when the scene is created).
+//
+// Point-light shadow tests are deferred the same way: Phong emits, per light that faces
+// the surface, a SHADOW entry carrying that light's finished Phong term; the caller runs
+// the any-hit query later, in the same traversal loop as every other ray, and adds the
+// term if the light is visible.  Lights whose sampling depends on earlier visibility
+// results (the square light's adaptive subdivision) are evaluated in place instead.
 #pragma once
 #include "rt_trace.h"
 
-struct Spawn {            // a secondary ray requested by the shader tree
+struct Spawn {            // a ray requested by the shader tree
     d3 o, d;
-    d3 w;                 // multiplies the ray's colour in this hit's colour
-    d3 c;                 // Ray::contribution of the new ray (ray.rs:22-26)
-    uint32_t ordinal;     // identifies the spawning shader + branch for the RNG path
+    d3 w;                 // RAY: multiplies the ray's colour in this hit's colour; SHADOW: the light's Phong term
+    d3 c;                 // RAY: Ray::contribution of the new ray (ray.rs:22-26); SHADOW: c.x = distance to the light
+    uint32_t ordinal;     // RAY: identifies the spawning shader + branch for the RNG path
+    uint32_t shadow;      // 1: visibility test whose colour `w` counts only if nothing blocks the light
 };
 
 // ------------------------------------------------------------------ images
@@ -38,8 +45,9 @@ RT_DEV d3 texture_color(const DScene& sc, uint32_t image, double u, double v) {
     return ((up_left * (1.0 - fu) * fv + up_right * fu * fv) + bot_left * (1.0 - fu) * (1.0 - fv)) + bot_right * fu * (1.0 - fv);
 }
 // Scene::get_background_color / SkyBox::get_color (src/scene.rs:99-106, 31-43)
+template <uint32_t F>
 RT_DEV d3 background_color(const DScene& sc, d3 dir) {
-    if (!sc.has_background) return mk3(0.0, 0.0, 0.0);
+    if (!(F & RTF_IMAGES) || !sc.has_background) return mk3(0.0, 0.0, 0.0);
     d3 d = normalize(xf_vector(sc.background_w2l, dir));
     double azimuth = atan2(d.z, d.x);
     double elevation = asin(d.y);
@@ -105,7 +113,14 @@ RT_DEV void phong_lit(PhongCtx& c, double surface_dot, d3 light_direction, d3 in
 // SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
 // an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
 // order so that the draw counter of the RNG advances identically.
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
+RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COUNT>& wk) {
+    SceneHit h;
+    RT_COUNT(wk, rays_shadow);
+    return trace_scene<F, COUNT>(sc, o, d, true, max_distance, h, wk);
+}
+
+template <uint32_t F, bool COUNT>
 RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
     struct Quad { double minx, miny, maxx, maxy; uint32_t depth; };
     Quad st[16];
@@ -136,7 +151,7 @@ RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_
             s_lit[s] = false;
             if (surface_dot <= 0.0) continue;
             double light_distance = length(hit_to_light);
-            if (trace_any<COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
+            if (occluded<F, COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
             s_lit[s] = true; s_dot[s] = surface_dot; s_dir[s] = light_direction;
             s_int[s] = lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
             lit_count++;
@@ -169,8 +184,11 @@ RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_
     }
 }
 
-template <bool COUNT>
-RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
+// PhongShader::get_color (src/shader/phong.rs:29-47).  Returns the part that is known now;
+// deferred point lights are appended to `spawn` as SHADOW entries.
+template <uint32_t F, bool COUNT>
+RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, uint64_t stream, uint32_t path,
+                      Spawn* spawn, uint32_t& nspawn, Work<COUNT>& wk) {
     PhongCtx c;
     c.p = p; c.n = n; c.view = -1.0 * ray_dir;
     c.diffuse = ld3(sh.p); c.specular = ld3(sh.p + 3); c.shininess = sh.p[9];
@@ -183,19 +201,32 @@ RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_di
             double surface_dot = dot(light_direction, n);
             if (surface_dot <= 0.0) continue;
             double light_distance = length(hit_to_light);
-            if (trace_any<COUNT>(sc, p, light_direction, light_distance, wk)) continue;
             d3 intensity = (L.power * ld3(L.color)) / (L.falloff[0] + L.falloff[1] * light_distance + L.falloff[2] * light_distance * light_distance) / 1.0;
-            RT_COUNT(wk, shade_evals);
-            phong_lit(c, surface_dot, light_direction, intensity);
-        } else if (L.kind == 1) {
-            square_light<COUNT>(sc, L, c, stream, path, wk);
-        } else {                                                  // DirectionLight, light.rs:104-119
-            d3 dir = ld3(L.position);
-            double surface_dot = dot(dir, n);
-            if (surface_dot <= 0.0) continue;
-            if (trace_any<COUNT>(sc, p, -1.0 * dir, INFINITY, wk)) continue;
-            RT_COUNT(wk, shade_evals);
-            phong_lit(c, surface_dot, -1.0 * dir, ld3(L.color) * L.power);
+            bool inline_test = (F & RTF_INLINE_LIGHTS) && sc.inline_point_lights;
+            if (inline_test) {
+                if constexpr (F & RTF_INLINE_LIGHTS) {
+                    if (occluded<F, COUNT>(sc, p, light_direction, light_distance, wk)) continue;
+                    RT_COUNT(wk, shade_evals);
+                    phong_lit(c, surface_dot, light_direction, intensity);
+                }
+            } else if (nspawn < RT_SHADE_MAX_SPAWN) {
+                PhongCtx one = c;
+                one.total = mk3(0.0, 0.0, 0.0);
+                phong_lit(one, surface_dot, light_direction, intensity);
+                Spawn& s = spawn[nspawn++];
+                s.o = p; s.d = light_direction; s.w = one.total; s.c = mk3(light_distance, 0.0, 0.0); s.ordinal = 0; s.shadow = 1;
+            }
+        } else if constexpr (F & RTF_INLINE_LIGHTS) {
+            if (L.kind == 1) {
+                square_light<F, COUNT>(sc, L, c, stream, path, wk);
+            } else {                                              // DirectionLight, light.rs:104-119
+                d3 dir = ld3(L.position);
+                double surface_dot = dot(dir, n);
+                if (surface_dot <= 0.0) continue;
+                if (occluded<F, COUNT>(sc, p, -1.0 * dir, INFINITY, wk)) continue;
+                RT_COUNT(wk, shade_evals);
+                phong_lit(c, surface_dot, -1.0 * dir, ld3(L.color) * L.power);
+            }
         }
     }
     return c.total;
@@ -228,7 +259,7 @@ RT_DEV void fresnel(d3 d, d3 n, double ior, double& kt, double& kr) {           
 // ------------------------------------------------------------------ shader-tree interpreter
 // Walks the material of a hit depth-first, left to right — the order in which the
 // reference's nested get_color calls run — and returns L; spawned rays go to `spawn`.
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit, d3 ray_dir, d3 ray_contrib,
                     uint64_t stream, uint32_t path, Spawn* spawn, uint32_t& nspawn, Work<COUNT>& wk) {
     struct Frame {
@@ -249,14 +280,18 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         const DShader& sh = sc.shaders[cur];
         bool returned = true;
         switch (sh.kind) {
-            case DS_PHONG: value = phong_color<COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, wk); break;
-            case DS_TEXTURE: value = texture_color(sc, sh.ref, hit.u, hit.v); break;           // shader/texture.rs:16-19
-            case DS_NORMAL_MAP: value = perturbed_normal(sc, sc.normal_maps[sh.ref], hit.u, hit.v, n, hit.tangent); break;   // shader.rs:170-173
+            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, spawn, nspawn, wk); break;
+            case DS_TEXTURE:                                                                  // shader/texture.rs:16-19
+                if constexpr (F & RTF_IMAGES) value = texture_color(sc, sh.ref, hit.u, hit.v); else value = mk3(0.0, 0.0, 0.0);
+                break;
+            case DS_NORMAL_MAP:                                                               // shader.rs:170-173
+                if constexpr (F & RTF_IMAGES) value = perturbed_normal(sc, sc.normal_maps[sh.ref], hit.u, hit.v, n, hit.tangent); else value = mk3(0.0, 0.0, 0.0);
+                break;
             case DS_REFLECTION: {                                                             // shader/reflection.rs:14-18
                 d3 k = ld3(sh.p);
                 if (nspawn < RT_SHADE_MAX_SPAWN) {
                     Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = k; s.c = cin * k; s.ordinal = cur * 4 + 0;
+                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = k; s.c = cin * k; s.ordinal = cur * 4 + 0; s.shadow = 0;
                 }
                 value = mk3(0.0, 0.0, 0.0);
                 break;
@@ -266,11 +301,11 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 fresnel(ray_dir, n, sh.p[3], kt, kr);
                 if (kt > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
                     Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = transmit_dir(ray_dir, n, sh.p[3]); s.w = mk3(kt, kt, kt); s.c = cin * kt; s.ordinal = cur * 4 + 1;
+                    s.o = hit.p; s.d = transmit_dir(ray_dir, n, sh.p[3]); s.w = mk3(kt, kt, kt); s.c = cin * kt; s.ordinal = cur * 4 + 1; s.shadow = 0;
                 }
                 if (kr > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
                     Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = mk3(kr, kr, kr); s.c = cin * kr; s.ordinal = cur * 4 + 2;
+                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = mk3(kr, kr, kr); s.c = cin * kr; s.ordinal = cur * 4 + 2; s.shadow = 0;
                 }
                 value = mk3(0.0, 0.0, 0.0);
                 break;
@@ -288,8 +323,10 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                     cur = sc.shader_child_idx[sh.first_child];
                     cin = f.cin * sc.shader_child_weight[sh.first_child];
                 } else {                                                                      // CHAIN shader.rs:134-152
-                    for (uint32_t k = 0; k < sh.nm_count; ++k)
-                        n = perturbed_normal(sc, sc.normal_maps[sc.chain_nmaps[sh.nm_begin + k]], hit.u, hit.v, n, hit.tangent);
+                    if constexpr (F & RTF_IMAGES) {
+                        for (uint32_t k = 0; k < sh.nm_count; ++k)
+                            n = perturbed_normal(sc, sc.normal_maps[sc.chain_nmaps[sh.nm_begin + k]], hit.u, hit.v, n, hit.tangent);
+                    }
                     f.cursor = sh.num_children - 1;
                     cur = sc.shader_child_idx[sh.first_child + sh.num_children - 1];
                     cin = f.cin;

@@ -16,6 +16,9 @@
 #define RT_MIN_CONTRIBUTION 0.003    // Ray::MIN_CONTRIBUTION, src/geometry/ray.rs:13
 #define RT_PI 3.14159265358979323846
 
+extern __shared__ __align__(16) uint8_t rt_lds_dynamic[];
+RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic; }
+
 struct LRay {            // a ray in some local space, direction normalised (ray.rs:90-97)
     d3 o, d;
 };
@@ -265,59 +268,103 @@ RT_DEV bool slab(const double* lo, const double* hi, d3 o, d3 inv, double tmax, 
     return tn <= tf && tf >= 0.0 && tn <= tmax;
 }
 
-// Closest triangle with t in (MIN_DISTANCE, tmax) [strict upper bound when !ANY], or —
-// with ANY — whether some triangle has t <= tmax (INCLUSIVE) / t < tmax.
-// Replaces BoundingNode::check_intersect (mesh.rs:167-279); the result is the same
-// closest hit because both structures are exact.
-template <bool ANY, bool COUNT>
-RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, double tmax, bool inclusive, double& t_out, uint32_t& tri_out, Work<COUNT>& wk) {
+RT_DEV bool slab_f32(const float* lo, const float* hi, d3 o, d3 inv, double tmax, double& tnear) {
+    double t0 = ((double)lo[0] - o.x) * inv.x, t1 = ((double)hi[0] - o.x) * inv.x;
+    double tn = fmin(t0, t1), tf = fmax(t0, t1);
+    t0 = ((double)lo[1] - o.y) * inv.y; t1 = ((double)hi[1] - o.y) * inv.y;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    t0 = ((double)lo[2] - o.z) * inv.z; t1 = ((double)hi[2] - o.z) * inv.z;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    tnear = tn;
+    return tn <= tf && tf >= 0.0 && tn <= tmax;
+}
+// Mesh::check_triangle (mesh.rs:416-443) on either triangle record
+template <class TRI>
+RT_DEV bool mesh_tri_test(const TRI& tr, const LRay& r, double& t) {
+    d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3), normal = ld3(tr.n);
+    double origin_dot = dot(normal, r.o - v1);
+    double direction_dot = dot(normal, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        if (dot(cross(v2 - v1, p - v1), normal) < 0.0) return false;
+        if (dot(cross(v3 - v2, p - v2), normal) < 0.0) return false;
+        if (dot(cross(v1 - v3, p - v3), normal) < 0.0) return false;
+        t = hit_distance;
+        return true;
+    }
+    return false;
+}
+
+// Closest triangle with t in (MIN_DISTANCE, tmax), or — with `any` — whether some triangle
+// has t <= tmax (inclusive) / t < tmax.  One routine serves both queries so that lanes
+// tracing shadow rays and lanes tracing camera/secondary rays share the same loop.
+// Replaces BoundingNode::check_intersect (mesh.rs:167-279); both structures are exact, so
+// the closest hit is the same.
+//
+// Shape of the walk ("while-while"): an inner loop descends through interior nodes until
+// the lane holds a leaf, then the leaf's triangles are tested.  Lanes of a wave therefore
+// sit together either in box tests or in triangle tests instead of interleaving the two,
+// which is what keeps the 64-wide vector unit filled on incoherent rays.
+// With LDS the node / triangle records come from the workgroup's LDS copy (LBvhNode /
+// LMeshTri), otherwise from the global-memory arrays.
+#define RT_WALK_DONE 0xFFFFFFFFu
+template <bool LDS, bool COUNT>
+RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any, double tmax, bool inclusive, double& t_out, uint32_t& tri_out, Work<COUNT>& wk) {
     d3 inv = mk3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     double tn;
     RT_COUNT(wk, box_tests);
     if (!slab(m.lo, m.hi, r.o, inv, tmax, tn)) return false;
-    const DBvhNode* nodes = sc.bvh_nodes + m.node_off;
-    const DMeshTri* tris = sc.mesh_tris + m.tri_off;
+    const DBvhNode* gnodes = sc.bvh_nodes + m.node_off;
+    const DMeshTri* gtris = sc.mesh_tris + m.tri_off;
+    const LBvhNode* lnodes = reinterpret_cast<const LBvhNode*>(rt_lds_base() + m.lds_node_off);
+    const LMeshTri* ltris = reinterpret_cast<const LMeshTri*>(rt_lds_base() + m.lds_tri_off);
     uint32_t stack[RT_BVH_STACK];
     int sp = 0;
     uint32_t cur = 0;
     bool found = false;
     double best = tmax;
-    for (;;) {
-        const DBvhNode& n = nodes[cur];
-        double tn0, tn1;
-        if (COUNT) wk.box_tests += 2;
-        bool h0 = slab(n.lo[0], n.hi[0], r.o, inv, best, tn0);
-        bool h1 = slab(n.lo[1], n.hi[1], r.o, inv, best, tn1);
-        uint32_t next = 0xFFFFFFFFu;
-        // visit order: nearer child first
-        int first = (h0 && h1 && tn1 < tn0) ? 1 : 0;
-        for (int k = 0; k < 2; ++k) {
-            int c = k == 0 ? first : 1 - first;
-            bool h = c == 0 ? h0 : h1;
-            if (!h) continue;
-            uint32_t ref = n.child[c];
-            if (ref & 0x80000000u) {
-                uint32_t base = ref & 0x7FFFFFFFu, cnt = n.count[c];
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    double t;
-                    RT_COUNT(wk, tri_tests);
-                    if (mesh_tri_hit(tris[base + i], r, t)) {
-                        if (ANY) {
-                            if (inclusive ? t <= tmax : t < tmax) return true;
-                        } else if (t < best) {
-                            best = t; tri_out = base + i; found = true;
-                        }
-                    }
-                }
-            } else if (next == 0xFFFFFFFFu) {
-                next = ref;
+    while (cur != RT_WALK_DONE) {
+        while (!(cur & 0x80000000u)) {                         // descend to a leaf
+            double tn0, tn1;
+            bool h0, h1;
+            uint32_t c0, c1;
+            if (COUNT) wk.box_tests += 2;
+            if (LDS) {
+                const LBvhNode& n = lnodes[cur];
+                h0 = slab_f32(n.lo[0], n.hi[0], r.o, inv, best, tn0);
+                h1 = slab_f32(n.lo[1], n.hi[1], r.o, inv, best, tn1);
+                c0 = n.child[0]; c1 = n.child[1];
             } else {
-                if (sp < RT_BVH_STACK) stack[sp++] = ref;
+                const DBvhNode& n = gnodes[cur];
+                h0 = slab(n.lo[0], n.hi[0], r.o, inv, best, tn0);
+                h1 = slab(n.lo[1], n.hi[1], r.o, inv, best, tn1);
+                c0 = n.child[0]; c1 = n.child[1];
+            }
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                cur = swap ? c1 : c0;
+                if (sp < RT_BVH_STACK) stack[sp++] = swap ? c0 : c1;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else cur = sp > 0 ? stack[--sp] : RT_WALK_DONE;
+        }
+        if (cur == RT_WALK_DONE) break;
+        uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+        for (uint32_t i = 0; i < cnt; ++i) {                     // the leaf's triangles
+            double t;
+            RT_COUNT(wk, tri_tests);
+            bool hit = LDS ? mesh_tri_test(ltris[base + i], r, t) : mesh_tri_test(gtris[base + i], r, t);
+            if (hit) {
+                if (any) {
+                    if (inclusive ? t <= tmax : t < tmax) { found = true; }
+                } else if (t < best) {
+                    best = t; tri_out = base + i; found = true;
+                }
             }
         }
-        if (next != 0xFFFFFFFFu) { cur = next; continue; }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (any && found) break;
+        cur = sp > 0 ? stack[--sp] : RT_WALK_DONE;
     }
     t_out = best;
     return found;
@@ -325,7 +372,7 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, double tm
 
 // ------------------------------------------------------------------ basic (non-composite) primitives
 // get_all_intersects of a primitive without wrappers: up to two hits, ascending.
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV int basic_hits(const DScene& sc, const DPrim& p, const LRay& r, double tmax_closest, Cand c[2], Work<COUNT>& wk) {
     switch (p.kind) {
         case DP_SPHERE: {
@@ -335,59 +382,72 @@ RT_DEV int basic_hits(const DScene& sc, const DPrim& p, const LRay& r, double tm
             return n;
         }
         case DP_RECTANGLE: { c[0].a = 0; c[0].b = 0; return rect_hit(p.p[0], p.p[1], r, c[0].t) ? 1 : 0; }
-        case DP_PLANE: { c[0].a = 0; c[0].b = 0; return plane_hit(p.p, r, c[0].t) ? 1 : 0; }
-        case DP_TRIANGLE: { c[0].a = 0; c[0].b = 0; return tri_hit(sc.tris[p.ref], r, c[0].t) ? 1 : 0; }
-        case DP_POLYGON: { c[0].a = 0; c[0].b = 0; return poly_hit(sc, sc.polys[p.ref], r, c[0].t) ? 1 : 0; }
-        case DP_FACED: {
-            double t[2]; uint32_t f[2];
-            int n = faced_hits(sc, sc.faced[p.ref], r, t, f);
-            for (int i = 0; i < n; ++i) { c[i].t = t[i]; c[i].a = f[i]; c[i].b = 0; }
-            return n;
-        }
-        case DP_POLYHEDRON: { c[0].b = 0; return polyhedron_hit(sc, p, r, c[0].t, c[0].a) ? 1 : 0; }
-        case DP_MESH: {
-            c[0].b = 0;
-            return mesh_walk<false, COUNT>(sc, sc.meshes[p.ref], r, tmax_closest, false, c[0].t, c[0].a, wk) ? 1 : 0;
-        }
+        case DP_PLANE: if constexpr (F & RTF_MISC) { c[0].a = 0; c[0].b = 0; return plane_hit(p.p, r, c[0].t) ? 1 : 0; } return 0;
+        case DP_TRIANGLE: if constexpr (F & RTF_MISC) { c[0].a = 0; c[0].b = 0; return tri_hit(sc.tris[p.ref], r, c[0].t) ? 1 : 0; } return 0;
+        case DP_POLYGON: if constexpr (F & RTF_MISC) { c[0].a = 0; c[0].b = 0; return poly_hit(sc, sc.polys[p.ref], r, c[0].t) ? 1 : 0; } return 0;
+        case DP_FACED:
+            if constexpr (F & RTF_FACED) {
+                double t[2]; uint32_t f[2];
+                int n = faced_hits(sc, sc.faced[p.ref], r, t, f);
+                for (int i = 0; i < n; ++i) { c[i].t = t[i]; c[i].a = f[i]; c[i].b = 0; }
+                return n;
+            }
+            return 0;
+        case DP_POLYHEDRON: if constexpr (F & RTF_MISC) { c[0].b = 0; return polyhedron_hit(sc, p, r, c[0].t, c[0].a) ? 1 : 0; } return 0;
+        case DP_MESH:
+            // un-wrapped meshes that are node primitives are walked by trace_scene itself; this
+            // site only serves meshes behind OneWay / Inverted or inside composite shapes
+            if constexpr ((F & RTF_MESH) && (F & (RTF_WRAP | RTF_CSG))) {
+                c[0].b = 0;
+                return mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], r, false, tmax_closest, false, c[0].t, c[0].a, wk) ? 1 : 0;
+            }
+            return 0;
         default: return 0;
     }
 }
+template <uint32_t F>
 RT_DEV void basic_details(const DScene& sc, const DPrim& p, const LRay& r, const Cand& c, Details& o) {
     switch (p.kind) {
         case DP_SPHERE: sphere_details(r, c.t, o); break;
         case DP_RECTANGLE: rect_details(p.p[0], p.p[1], r, c.t, o); break;
-        case DP_PLANE: plane_details(p.p, r, c.t, o); break;
-        case DP_TRIANGLE: tri_details(sc.tris[p.ref], r, c.t, o); break;
+        case DP_PLANE: if constexpr (F & RTF_MISC) plane_details(p.p, r, c.t, o); break;
+        case DP_TRIANGLE: if constexpr (F & RTF_MISC) tri_details(sc.tris[p.ref], r, c.t, o); break;
         case DP_POLYGON:
-            o.p = r.o + (c.t * r.d); o.n = ld3(sc.polys[p.ref].n); o.tangent = mk3(0.0, 1.0, 0.0);
-            surface_coord(0.0, 0.0, o.u, o.v);
+            if constexpr (F & RTF_MISC) {
+                o.p = r.o + (c.t * r.d); o.n = ld3(sc.polys[p.ref].n); o.tangent = mk3(0.0, 1.0, 0.0);
+                surface_coord(0.0, 0.0, o.u, o.v);
+            }
             break;
-        case DP_FACED: faced_details(sc, sc.faced[p.ref], r, c.a, o); break;
-        case DP_POLYHEDRON: {
-            plane_details(sc.prims[p.ref + c.a].p, r, c.t, o);
-            surface_coord(((double)c.a + o.u) / (double)p.count, o.v, o.u, o.v);   // polyhedron.rs:109-113
+        case DP_FACED: if constexpr (F & RTF_FACED) faced_details(sc, sc.faced[p.ref], r, c.a, o); break;
+        case DP_POLYHEDRON:
+            if constexpr (F & RTF_MISC) {
+                plane_details(sc.prims[p.ref + c.a].p, r, c.t, o);
+                surface_coord(((double)c.a + o.u) / (double)p.count, o.v, o.u, o.v);   // polyhedron.rs:109-113
+            }
             break;
-        }
-        case DP_MESH: {
-            const DMesh& m = sc.meshes[p.ref];
-            mesh_details(sc, m, sc.mesh_tris[m.tri_off + c.a], r, c.t, o);
+        case DP_MESH:
+            if constexpr (F & RTF_MESH) {
+                const DMesh& m = sc.meshes[p.ref];
+                mesh_details(sc, m, sc.mesh_tris[m.tri_off + c.a], r, c.t, o);
+            }
             break;
-        }
         default: break;
     }
     if (c.b & 1u) o.n = neg(o.n);
 }
 // n·d sign of a candidate, the quantity OneWay / Inverted / hit_direction test
+template <uint32_t F>
 RT_DEV double facing(const DScene& sc, const DPrim& p, const LRay& r, const Cand& c) {
     if (p.kind == DP_SPHERE && !(c.b & 1u)) return dot(r.d, r.o + (c.t * r.d));   // same sign as d·normalize(p)
     Details d;
-    basic_details(sc, p, r, c, d);
+    basic_details<F>(sc, p, r, c, d);
     return dot(r.d, d.n);
 }
 // Apply the OneWay / Inverted chain to a *closest* hit (src/primitive.rs:33-40, 64-72).
+template <uint32_t F>
 RT_DEV bool wrap_closest(const DScene& sc, const DPrim& p, const LRay& r, Cand& c) {
     for (uint32_t w = p.wrap; w; w >>= 2) {
-        double f = facing(sc, p, r, c);
+        double f = facing<F>(sc, p, r, c);
         if ((w & 3u) == DWRAP_ONEWAY) { if (!(f < 0.0)) return false; }
         else { if (!(f >= 0.0)) return false; c.b ^= 1u; }
     }
@@ -395,11 +455,12 @@ RT_DEV bool wrap_closest(const DScene& sc, const DPrim& p, const LRay& r, Cand& 
 }
 // Apply the chain to a get_all_intersects list (src/primitive.rs:42-45, 74-80): OneWay
 // filters, Inverted flips every normal without filtering.
+template <uint32_t F>
 RT_DEV int wrap_all(const DScene& sc, const DPrim& p, const LRay& r, Cand c[2], int n) {
     for (uint32_t w = p.wrap; w; w >>= 2) {
         if ((w & 3u) == DWRAP_ONEWAY) {
             int m = 0;
-            for (int i = 0; i < n; ++i) if (facing(sc, p, r, c[i]) < 0.0) c[m++] = c[i];
+            for (int i = 0; i < n; ++i) if (facing<F>(sc, p, r, c[i]) < 0.0) c[m++] = c[i];
             n = m;
         } else {
             for (int i = 0; i < n; ++i) c[i].b ^= 1u;
@@ -434,7 +495,7 @@ RT_DEV int csg_predicate(uint32_t kind, uint32_t cur, uint32_t states, uint32_t 
     }
     return 0;
 }
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, Cand& out, Work<COUNT>& wk) {
     CsgHit arena[RT_CSG_ARENA];
     uint32_t lbegin[RT_CSG_MAX_LISTS], lcount[RT_CSG_MAX_LISTS];
@@ -447,14 +508,14 @@ RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, C
             double s, inv_s;
             LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
             Cand c[2];
-            int n = basic_hits<COUNT>(sc, p, lr, INFINITY, c, wk);
-            if (p.wrap) n = wrap_all(sc, p, lr, c, n);
+            int n = basic_hits<F, COUNT>(sc, p, lr, INFINITY, c, wk);
+            if constexpr (F & RTF_WRAP) { if (p.wrap) n = wrap_all<F>(sc, p, lr, c, n); }
             lbegin[nl] = top; lcount[nl] = 0;
             for (int i = 0; i < n && top < RT_CSG_ARENA; ++i) {
                 CsgHit h;
                 h.t = c[i].t * inv_s;
                 h.leaf = op.leaf;
-                bool enter = facing(sc, p, lr, c[i]) < 0.0;        // hit_direction, composite_shape.rs:27-30
+                bool enter = facing<F>(sc, p, lr, c[i]) < 0.0;        // hit_direction, composite_shape.rs:27-30
                 h.meta = (enter ? 1u : 0u) | ((c[i].b & 1u) << 2) | ((uint32_t)i << 8);
                 arena[top++] = h; lcount[nl]++;
             }
@@ -496,7 +557,7 @@ RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, C
     out.b = ((h.meta >> 1) & 1u) | (((h.meta >> 2) & 1u) << 1) | ((h.meta >> 8) << 8);
     return true;
 }
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details& o, Work<COUNT>& wk) {
     const DCsgLeaf& leaf = sc.csg_leaves[c.a];
     const DPrim& p = sc.prims[leaf.prim];
@@ -504,11 +565,11 @@ RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details&
     LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
     Cand lc[2];
     Work<false> none;
-    int n = basic_hits<false>(sc, p, lr, INFINITY, lc, none);
-    if (p.wrap) n = wrap_all(sc, p, lr, lc, n);
+    int n = basic_hits<F, false>(sc, p, lr, INFINITY, lc, none);
+    if constexpr (F & RTF_WRAP) { if (p.wrap) n = wrap_all<F>(sc, p, lr, lc, n); }
     uint32_t idx = c.b >> 8;
     Details d;
-    basic_details(sc, p, lr, lc[idx < (uint32_t)n ? idx : 0], d);
+    basic_details<F>(sc, p, lr, lc[idx < (uint32_t)n ? idx : 0], d);
     o.p = xf_point(leaf.x.l2w, d.p);
     o.n = xf_normal(leaf.x.nmat, d.n);
     if (c.b & 1u) o.n = neg(o.n);
@@ -523,59 +584,60 @@ struct SceneHit {
     Cand c;              // in the instance's primitive space
 };
 
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk) {
-    if (p.kind == DP_CSG) return csg_closest<COUNT>(sc, sc.csg_roots[p.ref], lr, c, wk);
+    if constexpr (F & RTF_CSG) {
+        if (p.kind == DP_CSG) return csg_closest<F, COUNT>(sc, sc.csg_roots[p.ref], lr, c, wk);
+    }
     Cand cc[2];
     // an un-wrapped mesh may prune by the best distance so far; wrapped primitives must see their true closest hit
-    int n = basic_hits<COUNT>(sc, p, lr, p.wrap ? INFINITY : tmax_local, cc, wk);
+    bool wrapped = (F & RTF_WRAP) && p.wrap;
+    int n = basic_hits<F, COUNT>(sc, p, lr, wrapped ? INFINITY : tmax_local, cc, wk);
     if (n == 0) return false;
     c = cc[0];
-    if (p.wrap) return wrap_closest(sc, p, lr, c);
+    if constexpr (F & RTF_WRAP) { if (p.wrap) return wrap_closest<F>(sc, p, lr, c); }
     return true;
 }
 
-// Scene::cast_ray's root.trace(ray) (src/scene.rs:68, 196-225): closest hit over all instances,
-// strict '<' with earlier instances winning ties (own primitive before children, children in order).
-template <bool COUNT>
-RT_DEV bool trace_closest(const DScene& sc, d3 o, d3 d, SceneHit& hit, Work<COUNT>& wk) {
+// One scene query for both kinds of ray:
+//   any == false: Scene::cast_ray's root.trace(ray) (src/scene.rs:68, 196-225) — closest hit over
+//                 all instances, strict '<', earlier instances (DFS pre-order) win ties;
+//   any == true:  SceneNode::partial_trace_until_distance (src/scene.rs:227-248) — does anything
+//                 lie closer than max_distance ('<=' for the root's own primitive, '<' below it)?
+template <uint32_t F, bool COUNT>
+RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk) {
     bool found = false;
-    double best = INFINITY;
-    for (uint32_t i = 0; i < sc.num_instances; ++i) {
-        const DInstance& in = sc.instances[i];
-        double s, inv_s;
-        LRay lr = to_local(in.x, o, d, s, inv_s);
-        Cand c;
-        RT_COUNT(wk, instance_tests);
-        if (!prim_closest<COUNT>(sc, sc.prims[in.prim], lr, best * s, c, wk)) continue;
-        double tw = c.t * inv_s;
-        if (tw < best) { best = tw; hit.inst = i; hit.c = c; found = true; }
-    }
-    hit.t = best;
-    return found;
-}
-
-// SceneNode::partial_trace_until_distance (src/scene.rs:227-248): is anything closer than the light?
-template <bool COUNT>
-RT_DEV bool trace_any(const DScene& sc, d3 o, d3 d, double max_distance, Work<COUNT>& wk) {
-    RT_COUNT(wk, rays_shadow);
+    double best = any ? max_distance : INFINITY;
     for (uint32_t i = 0; i < sc.num_instances; ++i) {
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
         double s, inv_s;
         LRay lr = to_local(in.x, o, d, s, inv_s);
-        double max_local = max_distance * s;
         RT_COUNT(wk, instance_tests);
-        if (p.kind == DP_MESH && !p.wrap) {
-            double t; uint32_t tri;
-            if (mesh_walk<true, COUNT>(sc, sc.meshes[p.ref], lr, max_local, in.is_root != 0, t, tri, wk)) return true;
-            continue;
-        }
         Cand c;
-        if (!prim_closest<COUNT>(sc, p, lr, INFINITY, c, wk)) continue;
-        if (in.is_root ? c.t <= max_local : c.t < max_local) return true;
+        bool got;
+        bool direct_mesh = false;
+        if constexpr (F & RTF_MESH) direct_mesh = p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap);
+        if (direct_mesh) {
+            if constexpr (F & RTF_MESH) {
+                // one call site for both query kinds: shadow lanes and camera/secondary lanes walk together
+                c.b = 0;
+                got = mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], lr, any, best * s, in.is_root != 0, c.t, c.a, wk);
+                if (any) { if (got) return true; continue; }
+            }
+        } else {
+            got = prim_closest<F, COUNT>(sc, p, lr, any ? INFINITY : best * s, c, wk);
+            if (any) {
+                if (got && (in.is_root ? c.t <= max_distance * s : c.t < max_distance * s)) return true;
+                continue;
+            }
+        }
+        if (!got) continue;
+        double tw = c.t * inv_s;
+        if (tw < best) { best = tw; hit.inst = i; hit.c = c; found = true; }
     }
-    return false;
+    hit.t = best;
+    return found;
 }
 
 // Rebuild the world-space Intersect of the winning hit (geometry/intersect.rs:31-45 applied
@@ -585,15 +647,18 @@ struct WorldHit {
     double u, v;
     uint32_t inst;
 };
-template <bool COUNT>
+template <uint32_t F, bool COUNT>
 RT_DEV void world_hit(const DScene& sc, d3 o, d3 d, const SceneHit& h, WorldHit& w, Work<COUNT>& wk) {
     const DInstance& in = sc.instances[h.inst];
     const DPrim& p = sc.prims[in.prim];
     double s, inv_s;
     LRay lr = to_local(in.x, o, d, s, inv_s);
     Details dt;
-    if (p.kind == DP_CSG) csg_details<COUNT>(sc, lr, h.c, dt, wk);
-    else basic_details(sc, p, lr, h.c, dt);
+    bool done = false;
+    if constexpr (F & RTF_CSG) {
+        if (p.kind == DP_CSG) { csg_details<F, COUNT>(sc, lr, h.c, dt, wk); done = true; }
+    }
+    if (!done) basic_details<F>(sc, p, lr, h.c, dt);
     w.p = xf_point(in.x.l2w, dt.p);
     w.n = xf_normal(in.x.nmat, dt.n);
     w.tangent = xf_vector(in.x.l2w, dt.tangent);
