@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -65,6 +66,8 @@ struct RtScene {
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
+    DeviceBuf queue[2], acc, acc_flags, acc_out;   // hand-over queues between rounds, split-sample accumulators
+    bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -90,7 +93,8 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
-    for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full}) b->release();
+    for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
+                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->acc_out}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -194,6 +198,24 @@ int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t strea
     return launch_variant<RTF_ALL>(count, grid, stream, ds, rp, ta);
 }
 
+// Layout of the per-frame scalar block (u32 words), zeroed at the start of every frame.
+constexpr uint32_t RT_MAX_ROUNDS = 40;
+constexpr uint32_t SC_AA_COUNT = 0, SC_ACC_ALLOC0 = 1, SC_ACC_ALLOC1 = 2;
+constexpr uint32_t SC_NEXT0 = 16, SC_NEXT1 = SC_NEXT0 + RT_MAX_ROUNDS + 1;          // work counters, one per round
+constexpr uint32_t SC_QUEUE0 = SC_NEXT1 + RT_MAX_ROUNDS + 1, SC_QUEUE1 = SC_QUEUE0 + RT_MAX_ROUNDS + 1;   // queue fill, one per round
+constexpr size_t SCALAR_BYTES = 1024;
+static_assert((SC_QUEUE1 + RT_MAX_ROUNDS + 1) * 4 <= SCALAR_BYTES, "scalar block too small");
+
+uint32_t trace_budget() {
+    static const uint32_t b = [] { const char* e = std::getenv("RT_TRACE_BUDGET"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 24u; }();
+    return b;
+}
+uint32_t trace_rounds(uint32_t recursion_depth) {
+    static const long forced = [] { const char* e = std::getenv("RT_TRACE_ROUNDS"); return e ? std::atol(e) : 0L; }();
+    if (forced > 0) return (uint32_t)std::min<long>(forced, RT_MAX_ROUNDS);
+    return std::min(recursion_depth + 1, RT_MAX_ROUNDS);
+}
+
 int check_args(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg) {
     if (!scene || !dim || !cam || !cfg) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (dim->width == 0 || dim->height == 0) return fail(RT_ERR_INVALID_ARG, "rt_render: empty image");
@@ -256,12 +278,26 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     if ((e = s->distance.ensure(npix * sizeof(double))) != RT_OK) return e;
     if ((e = s->hit_id.ensure(npix * sizeof(uint32_t))) != RT_OK) return e;
     if ((e = s->mask.ensure(npix)) != RT_OK) return e;
-    if ((e = s->scalars.ensure(256 + sizeof(DCounters))) != RT_OK) return e;
-    unsigned int* next_tile = static_cast<unsigned int*>(s->scalars.p);          // [0]
-    unsigned int* aa_count = next_tile + 1;                                       // [1]
-    unsigned int* next_chunk = next_tile + 2;                                     // [2]
-    DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(s->scalars.p) + 256);
-    HIP_TRY(hipMemsetAsync(s->scalars.p, 0, 256 + sizeof(DCounters), stream));
+    if ((e = s->scalars.ensure(SCALAR_BYTES + sizeof(DCounters))) != RT_OK) return e;
+    unsigned int* scalars = static_cast<unsigned int*>(s->scalars.p);
+    unsigned int* aa_count = scalars + SC_AA_COUNT;
+    DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(s->scalars.p) + SCALAR_BYTES);
+    HIP_TRY(hipMemsetAsync(s->scalars.p, 0, SCALAR_BYTES + sizeof(DCounters), stream));
+    // hand-over queues and accumulators for samples split across rounds
+    const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 16), 1u << 25);
+    const uint32_t acc_cap = (uint32_t)std::min<size_t>(npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u), 1u << 23);
+    for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(SpillItem))) != RT_OK) return e;
+    {
+        bool fresh = s->acc.bytes < (size_t)acc_cap * RT_ACC_LIMBS * 8;
+        if ((e = s->acc.ensure((size_t)acc_cap * RT_ACC_LIMBS * 8)) != RT_OK) return e;
+        if ((e = s->acc_flags.ensure((size_t)acc_cap * 4)) != RT_OK) return e;
+        if ((e = s->acc_out.ensure((size_t)acc_cap * 4)) != RT_OK) return e;
+        if (fresh || s->acc_dirty) {
+            HIP_TRY(hipMemsetAsync(s->acc.p, 0, s->acc.bytes, stream));
+            HIP_TRY(hipMemsetAsync(s->acc_flags.p, 0, s->acc_flags.bytes, stream));
+        }
+        s->acc_dirty = true;
+    }
     HIP_TRY(hipMemsetAsync(s->mask.p, 0, npix, stream));
     if (rp.nranks > 1) {   // rows never rendered by this rank must not look like data
         HIP_TRY(hipMemsetAsync(s->color.p, 0, npix * 3 * sizeof(double), stream));
@@ -281,10 +317,35 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     TraceArgs ta{};
     ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
     ta.color = (double*)s->color.p; ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
-    ta.list = nullptr; ta.count = aa_count; ta.samples = nullptr; ta.next_item = next_tile; ta.counters = counters; ta.mode = 0;
+    ta.list = nullptr; ta.count = aa_count; ta.samples = nullptr; ta.counters = counters; ta.mode = 0;
+    ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)s->acc.p; ta.acc_flags = (uint32_t*)s->acc_flags.p;
+    ta.acc_out = (uint32_t*)s->acc_out.p; ta.acc_cap = acc_cap;
+    // Rounds: every round but the last hands rays on once an item has used its budget; a chain of
+    // secondary rays advances at least one level per round, so recursion_depth + 1 rounds reach
+    // every ray and the unbudgeted last round only sees leftovers.  Rounds with an empty queue
+    // return at once.
+    const uint32_t rounds = trace_rounds(rc.recursion_depth);
+    auto run_rounds = [&](uint32_t mode, uint32_t first_grid, double* dst) -> int {
+        ta.mode = mode;
+        ta.acc_alloc = scalars + (mode == 0 ? SC_ACC_ALLOC0 : SC_ACC_ALLOC1);
+        for (uint32_t r = 0; r < rounds; ++r) {
+            ta.round = r;
+            ta.budget = r + 1 < rounds ? trace_budget() : 0xFFFFFFFFu;
+            ta.next_item = scalars + (mode == 0 ? SC_NEXT0 : SC_NEXT1) + r;
+            ta.in_items = (const SpillItem*)s->queue[r & 1].p;
+            ta.in_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r;
+            ta.out_items = (SpillItem*)s->queue[(r + 1) & 1].p;
+            ta.out_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r + 1;
+            int lrc = launch_trace(s->ds.features, count_work, r == 0 ? first_grid : max_waves, stream, s->ds, rp, ta);
+            if (lrc != RT_OK) return lrc;
+        }
+        hipLaunchKernelGGL(k_acc_resolve, dim3(1024), dim3(256), 0, stream, ta.acc, ta.acc_flags, (const uint32_t*)ta.acc_out,
+                           (const unsigned int*)ta.acc_alloc, acc_cap, dst);
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    };
     if (num_rows > 0) {
-        uint32_t grid = std::min(tiles, max_waves);
-        int lrc = launch_trace(s->ds.features, count_work, grid, stream, s->ds, rp, ta);
+        int lrc = run_rounds(0, std::min(tiles, max_waves), (double*)s->color.p);
         if (lrc != RT_OK) return lrc;
     }
     HIP_TRY(hipEventRecord(s->ev[1], stream));
@@ -297,8 +358,8 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, (const double*)s->distance.p,
                            (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
         HIP_TRY(hipGetLastError());
-        ta.list = (const uint32_t*)s->list.p; ta.samples = (double*)s->samples.p; ta.next_item = next_chunk; ta.mode = 1;
-        int lrc = launch_trace(s->ds.features, count_work, max_waves, stream, s->ds, rp, ta);
+        ta.list = (const uint32_t*)s->list.p; ta.samples = (double*)s->samples.p;
+        int lrc = run_rounds(1, max_waves, (double*)s->samples.p);
         if (lrc != RT_OK) return lrc;
         hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
                            (const double*)s->samples.p, (double*)s->color.p, (double*)s->distance.p);
@@ -312,6 +373,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     }
     HIP_TRY(hipEventRecord(s->ev[3], stream));
     s->timed = true;
+    s->acc_dirty = false;
     return RT_OK;
 }
 
@@ -352,8 +414,8 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
         if (count) {   // counters are host-visible results: this variant of the call synchronises
             DCounters c{};
             unsigned int aa = 0;
-            HIP_TRY(hipMemcpyAsync(&c, static_cast<char*>(s->scalars.p) + 256, sizeof c, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + 4, sizeof aa, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
             fill_counters(d_aux->counters, c);
@@ -405,8 +467,8 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             if (aux->aa_mask) HIP_TRY(hipMemcpy(aux->aa_mask, s->mask.p, npix, hipMemcpyDeviceToHost));
             DCounters c{};
             unsigned int aa = 0;
-            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + 256, sizeof c, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + 4, sizeof aa, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
             fill_counters(aux->counters, c);
         }

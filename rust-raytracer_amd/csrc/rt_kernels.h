@@ -25,6 +25,61 @@ struct StackRay {         // one pending ray (Ray of src/geometry/ray.rs:4-9 plu
 };
 #define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
+// Load balancing across launches.  The cost of a camera sample is wildly uneven (a wall pixel
+// is 4 rays, a pixel through the glass mesh can be ten thousand, all serial in one lane), so a
+// launch gives every work item a budget of ray steps.  Once the budget is used up the lane stops
+// tracing camera/secondary rays of that item: each one still pending on its stack is written to
+// a queue in global memory and becomes a work item of its own in the next launch ("round").
+// Every part of a split sample adds its share of the colour into a fixed-point accumulator
+// (integer adds commute, so the sum does not depend on the order in which lanes finish);
+// k_acc_resolve turns the accumulators back into f64.
+struct SpillItem {        // 112 bytes
+    double o[3], d[3], w[3], c[3];
+    uint32_t depth, path;
+    uint32_t out;         // output slot: pixel index (pass 1) or sample index (AA resolve)
+    uint32_t acc_slot;
+};
+#define RT_NO_SLOT 0xFFFFFFFFu
+#define RT_ACC_LIMBS 9    // 3 channels x 3 signed limbs of weight 2^0, 2^-40, 2^-80
+
+// One unique index per calling lane from a shared counter, one atomic per wave.
+RT_DEV uint32_t wave_alloc(unsigned int* counter) {
+    unsigned long long m = __ballot(1);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Adds v into three signed 64-bit limbs (exact for |v| in [2^-27, 2^40); smaller parts are cut
+// at 2^-80).  Non-finite and absurdly large values are recorded as flags instead.
+RT_DEV void acc_add(unsigned long long* limbs, uint32_t* flags, uint32_t channel, double v) {
+    if (!(fabs(v) < 0x1p40)) {
+        uint32_t bit = (v != v) ? 4u : (v > 0.0 ? 1u : 2u);
+        atomicOr(flags, bit << (3u * channel));
+        return;
+    }
+    double l0 = trunc(v);
+    double r1 = (v - l0) * 0x1p40;
+    double l1 = trunc(r1);
+    double l2 = trunc((r1 - l1) * 0x1p40);
+    unsigned long long* a = limbs + 3u * channel;
+    if (l0 != 0.0) atomicAdd(a, (unsigned long long)(long long)l0);
+    if (l1 != 0.0) atomicAdd(a + 1, (unsigned long long)(long long)l1);
+    if (l2 != 0.0) atomicAdd(a + 2, (unsigned long long)(long long)l2);
+}
+RT_DEV double acc_value(const unsigned long long* limbs, uint32_t flags, uint32_t channel) {
+    uint32_t f = (flags >> (3u * channel)) & 7u;
+    if (f) {
+        if ((f & 4u) || (f & 3u) == 3u) return NAN;
+        return (f & 1u) ? INFINITY : -INFINITY;
+    }
+    const unsigned long long* a = limbs + 3u * channel;
+    return ((double)(long long)a[2] * 0x1p-80 + (double)(long long)a[1] * 0x1p-40) + (double)(long long)a[0];
+}
+
 // calculate_pixel_location + Ray::from_destination (src/render.rs:127-132,167-168).
 // (px, py) already include the caller's +0.5; the closure adds another 0.5.
 RT_DEV d3 camera_dir(const DCamera& cam, double px, double py) {
@@ -67,11 +122,26 @@ struct TraceArgs {
     unsigned int* next_item;  // global work counter
     DCounters* counters;
     uint32_t mode;
+    // rounds: round 0 takes its items from the image / the AA list, round r > 0 from in_items
+    uint32_t round;
+    uint32_t budget;          // ray steps per item before its pending rays are handed to the next round
+    const SpillItem* in_items;
+    const unsigned int* in_count;
+    SpillItem* out_items;
+    unsigned int* out_count;
+    uint32_t queue_cap;
+    unsigned long long* acc;  // acc_cap x RT_ACC_LIMBS, all zero between frames
+    uint32_t* acc_flags;      // acc_cap
+    uint32_t* acc_out;        // acc_cap: output slot of each accumulator
+    unsigned int* acc_alloc;
+    uint32_t acc_cap;
 };
 
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__((F & RTF_LDS_BVH) ? 512 : 64)
 k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
+    const uint32_t queued = a.round > 0 ? min(*a.in_count, a.queue_cap) : 0u;
+    if (a.round > 0 && queued == 0) return;                         // nothing was handed on: uniform exit
     if constexpr (F & RTF_LDS_BVH) {
         // stage every mesh's BVH nodes and triangles into LDS once per workgroup
         const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);
@@ -83,7 +153,8 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (W + 7) / 8;
     uint32_t total;
-    if (a.mode == 0) total = tiles_x * ((a.num_rows + 7) / 8) * 64;
+    if (a.round > 0) total = queued;
+    else if (a.mode == 0) total = tiles_x * ((a.num_rows + 7) / 8) * 64;
     else total = *a.count * rp.aa_rays;
     const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
     const d3 cam_o = ld3(rp.cam.origin);
@@ -95,6 +166,8 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     // the sample this lane is working on
     bool active = false, exhausted = false, first = true;
     uint32_t item = 0;
+    uint32_t steps = 0;                 // ray steps spent on the current item
+    uint32_t acc_slot = RT_NO_SLOT;     // accumulator of the current item's sample once it has been split
     size_t out_index = 0;
     uint64_t stream = 0;
     d3 color = mk3(0.0, 0.0, 0.0);
@@ -106,12 +179,19 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     for (;;) {
         // ---------------- finish / refill
         if (active && sp == 0) {
-            if (a.mode == 0) {
+            if (acc_slot != RT_NO_SLOT) {
+                unsigned long long* limbs = a.acc + (size_t)acc_slot * RT_ACC_LIMBS;
+                acc_add(limbs, a.acc_flags + acc_slot, 0, color.x);
+                acc_add(limbs, a.acc_flags + acc_slot, 1, color.y);
+                acc_add(limbs, a.acc_flags + acc_slot, 2, color.z);
+            } else if (a.mode == 0) {
                 a.color[3 * out_index] = color.x; a.color[3 * out_index + 1] = color.y; a.color[3 * out_index + 2] = color.z;
-                a.distance[out_index] = distance;
-                a.hit_id[out_index] = hit_id;
             } else {
                 a.samples[3 * out_index] = color.x; a.samples[3 * out_index + 1] = color.y; a.samples[3 * out_index + 2] = color.z;
+            }
+            if (a.mode == 0 && a.round == 0) {
+                a.distance[out_index] = distance;
+                a.hit_id[out_index] = hit_id;
             }
             active = false;
         }
@@ -140,7 +220,20 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                     // ---- set up the camera sample
                     d3 dir;
                     bool valid = true;
-                    if (a.mode == 0) {
+                    steps = 0;
+                    if (a.round > 0) {
+                        // a ray handed on by the previous round: a work item of its own
+                        const SpillItem& it = a.in_items[item];
+                        out_index = it.out;
+                        acc_slot = it.acc_slot;
+                        if (a.mode == 0) stream = rng_stream(rp.seed, out_index, 0);
+                        else stream = rng_stream(rp.seed, a.list[it.out / rp.aa_rays], 1 + it.out % rp.aa_rays);
+                        active = true; first = false; valid = false;
+                        color = mk3(0.0, 0.0, 0.0);
+                        stack[0].o = ld3(it.o); stack[0].d = ld3(it.d); stack[0].w = ld3(it.w); stack[0].c = ld3(it.c);
+                        stack[0].depth = it.depth; stack[0].path = it.path;
+                        sp = 1;
+                    } else if (a.mode == 0) {
                         uint32_t tile = item >> 6, within = item & 63u;
                         uint32_t x = (tile % tiles_x) * 8 + (within & 7u), ry = (tile / tiles_x) * 8 + (within >> 3);
                         if (x >= W || ry >= a.num_rows) valid = false;
@@ -164,7 +257,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                         out_index = item;
                     }
                     if (valid) {
-                        active = true; first = true;
+                        active = true; first = true; acc_slot = RT_NO_SLOT;
                         color = mk3(0.0, 0.0, 0.0); distance = INFINITY; hit_id = 0xFFFFFFFFu;
                         stack[0].o = cam_o; stack[0].d = dir;
                         stack[0].w = mk3(1.0, 1.0, 1.0); stack[0].c = mk3(1.0, 1.0, 1.0);
@@ -187,10 +280,32 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                 first = false;
                 continue;
             }
+            if (steps >= a.budget) {
+                // out of budget: this ray and its whole subtree go to the next round
+                if (acc_slot == RT_NO_SLOT) {
+                    uint32_t slot = wave_alloc(a.acc_alloc);
+                    if (slot < a.acc_cap) { acc_slot = slot; a.acc_out[slot] = (uint32_t)out_index; }
+                }
+                if (acc_slot != RT_NO_SLOT) {
+                    uint32_t q = wave_alloc(a.out_count);
+                    if (q < a.queue_cap) {
+                        SpillItem& it = a.out_items[q];
+                        it.o[0] = r.o.x; it.o[1] = r.o.y; it.o[2] = r.o.z;
+                        it.d[0] = r.d.x; it.d[1] = r.d.y; it.d[2] = r.d.z;
+                        it.w[0] = r.w.x; it.w[1] = r.w.y; it.w[2] = r.w.z;
+                        it.c[0] = r.c.x; it.c[1] = r.c.y; it.c[2] = r.c.z;
+                        it.depth = r.depth; it.path = r.path;
+                        it.out = (uint32_t)out_index; it.acc_slot = acc_slot;
+                        continue;
+                    }
+                }
+                // no room: trace it here after all
+            }
             if (COUNT) { if (first) cam++; else wk.rays_secondary++; }
         } else {
             RT_COUNT(wk, rays_shadow);
         }
+        ++steps;
         SceneHit h;
         bool found = trace_scene<F, COUNT>(sc, r.o, r.d, shadow, r.c.x, h, wk);
         if (shadow) {
@@ -225,6 +340,22 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     }
     if (a.mode == 0) flush_counters<COUNT>(a.counters, wk, cam, 0);
     else flush_counters<COUNT>(a.counters, wk, 0, cam);
+}
+
+// ------------------------------------------------------------------ split samples: accumulators -> f64
+// dst is the colour buffer (pass 1) or the AA sample buffer; leaves every accumulator zero again.
+__global__ void __launch_bounds__(256)
+k_acc_resolve(unsigned long long* __restrict__ acc, uint32_t* __restrict__ acc_flags, const uint32_t* __restrict__ acc_out,
+              const unsigned int* __restrict__ acc_alloc, uint32_t acc_cap, double* __restrict__ dst) {
+    uint32_t n = min(*acc_alloc, acc_cap);
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        unsigned long long* limbs = acc + (size_t)slot * RT_ACC_LIMBS;
+        uint32_t f = acc_flags[slot];
+        size_t out = acc_out[slot];
+        for (uint32_t ch = 0; ch < 3; ++ch) dst[3 * out + ch] = acc_value(limbs, f, ch);
+        for (uint32_t i = 0; i < RT_ACC_LIMBS; ++i) limbs[i] = 0ull;
+        acc_flags[slot] = 0u;
+    }
 }
 
 // ------------------------------------------------------------------ AA detect (src/render.rs:202-220)
