@@ -66,7 +66,7 @@ struct RtScene {
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
-    DeviceBuf queue[2], acc, acc_flags, acc_out;   // hand-over queues between rounds, split-sample accumulators
+    DeviceBuf queue[2], acc, acc_flags, acc_out, lane_mem;   // hand-over queues between rounds, split-sample accumulators
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -94,7 +94,7 @@ void rt_scene_destroy(RtScene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
     for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
-                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->acc_out}) b->release();
+                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->acc_out, &s->lane_mem}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -122,7 +122,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     DScene& d = s->ds;
     int rc = RT_OK;
 #define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
-    UP(instances, fs.instances); UP(prims, fs.prims); UP(tris, fs.tris); UP(polys, fs.polys); UP(points, fs.points);
+    UP(instances, fs.instances); UP(mesh_instances, fs.mesh_instances); UP(prims, fs.prims); UP(tris, fs.tris); UP(polys, fs.polys); UP(points, fs.points);
     UP(faced, fs.faced); UP(meshes, fs.meshes); UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris);
     UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(csg_roots, fs.csg_roots); UP(csg_ops, fs.csg_ops);
     UP(csg_leaves, fs.csg_leaves); UP(shaders, fs.shaders); UP(shader_child_idx, fs.shader_child_idx);
@@ -131,6 +131,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
     d.num_instances = (uint32_t)fs.instances.size();
+    d.num_mesh_instances = (uint32_t)fs.mesh_instances.size();
     d.num_lights = (uint32_t)fs.lights.size();
     std::memcpy(d.ambient, fs.ambient, sizeof d.ambient);
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
@@ -142,7 +143,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
         s->lds_limit = lds_max > 0 ? (uint32_t)lds_max : 65536u;
         d.lds_blob = nullptr; d.lds_blob_bytes = 0;
-        if ((fs.features & RTF_MESH) && !fs.lds_blob.empty() && fs.lds_blob.size() <= s->lds_limit) {
+        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + 512u * RT_LDS_STACK * 4u <= s->lds_limit) {
             rc = upload(fs.lds_blob, s->owned, &d.lds_blob);
             if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
             d.lds_blob_bytes = (uint32_t)fs.lds_blob.size();
@@ -170,9 +171,9 @@ namespace {
 template <uint32_t F>
 int launch_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
     uint32_t block = 64, lds = 0;
-    if (F & RTF_LDS_BVH) {   // one 512-thread workgroup per CU, the BVH blob in its LDS
-        block = 512; lds = ds.lds_blob_bytes;
-        grid = std::max(1u, grid / 16);
+    if (F & RTF_LDS_BVH) { block = 512; grid = std::max(1u, grid / 8); }   // one 512-thread workgroup per CU, the BVH blob in its LDS
+    if (F & RTF_MESH) lds = block * RT_LDS_STACK * 4u + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // BVH walk stacks (+ blob)
+    if (lds > 48u * 1024u) {
         auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea));
@@ -307,17 +308,23 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
 
     // persistent grid: enough waves to fill every CU several times over; each pulls tiles until none are left
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
-    const uint32_t max_waves = (uint32_t)s->num_cus * 16;
+    const uint32_t max_waves = (uint32_t)s->num_cus * 8;           // two waves per SIMD: all the register file allows
+    if ((e = s->lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
-    {
-        uint64_t need = (uint64_t)(s->ds.max_ray_spawn > 0 ? s->ds.max_ray_spawn - 1 : 0) * rc.recursion_depth + 1 + s->ds.max_shadow_spawn + s->ds.max_ray_spawn;
-        if (need > RT_MAX_STACK) return fail(RT_ERR_CAPACITY, "rt_render: recursion_depth x rays-per-hit exceeds the device ray stack");
+    // With b rays taken per trip up to b x (spawn - 1) entries stay behind per level, and the last trip's pushes sit on top.
+    uint32_t batch = (s->ds.features & RTF_MESH) ? RT_BATCH : 1;
+    for (;; --batch) {
+        uint64_t per_level = s->ds.max_ray_spawn > 0 ? s->ds.max_ray_spawn - 1 : 0;
+        uint64_t need = batch * (per_level * rc.recursion_depth + s->ds.max_shadow_spawn + s->ds.max_ray_spawn) + 1;
+        if (need <= RT_MAX_STACK && batch * s->ds.max_shadow_spawn <= RT_MAX_SHADOW_JOBS) break;
+        if (batch == 1) return fail(RT_ERR_CAPACITY, "rt_render: recursion_depth x rays-per-hit exceeds the device ray stack");
     }
     TraceArgs ta{};
     ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
     ta.color = (double*)s->color.p; ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
     ta.list = nullptr; ta.count = aa_count; ta.samples = nullptr; ta.counters = counters; ta.mode = 0;
+    ta.batch = batch; ta.lane_mem = (uint8_t*)s->lane_mem.p;
     ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)s->acc.p; ta.acc_flags = (uint32_t*)s->acc_flags.p;
     ta.acc_out = (uint32_t*)s->acc_out.p; ta.acc_cap = acc_cap;
     // Rounds: every round but the last hands rays on once an item has used its budget; a chain of
@@ -471,6 +478,15 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
             fill_counters(aux->counters, c);
+        }
+        if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
+            unsigned int sc[SCALAR_BYTES / 4];
+            HIP_TRY(hipMemcpy(sc, s->scalars.p, SCALAR_BYTES, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[rt] split samples: pass1 %u aa %u\n[rt] queue pass1:", sc[SC_ACC_ALLOC0], sc[SC_ACC_ALLOC1]);
+            for (uint32_t r = 1; r <= RT_MAX_ROUNDS && sc[SC_QUEUE0 + r]; ++r) std::fprintf(stderr, " %u", sc[SC_QUEUE0 + r]);
+            std::fprintf(stderr, "\n[rt] queue aa:");
+            for (uint32_t r = 1; r <= RT_MAX_ROUNDS && sc[SC_QUEUE1 + r]; ++r) std::fprintf(stderr, " %u", sc[SC_QUEUE1 + r]);
+            std::fprintf(stderr, "\n");
         }
     }
     if (aux) {

@@ -14,8 +14,11 @@
 #pragma once
 #include <stdint.h>
 
-#define RT_MAX_STACK 64        // secondary-ray stack entries per camera sample
-#define RT_BVH_STACK 48        // BVH traversal stack entries
+#define RT_MAX_STACK 128       // secondary-ray stack entries per camera sample
+#define RT_BATCH 4             // rays a lane takes off its stack per trip when the scene has meshes
+#define RT_BVH_STACK 48        // BVH traversal stack entries (deeper trees are rejected at scene creation)
+#define RT_LDS_STACK 24        // ... of which this many live in LDS, the rest in the lane's global memory
+#define RT_MAX_SHADOW_JOBS 32  // deferred shadow tests a lane may hold between two trips
 #define RT_CSG_MAX_HITS 16     // hits per composite-shape list
 #define RT_CSG_ARENA 96        // hits across all live lists of one composite query
 #define RT_CSG_MAX_LISTS 12
@@ -94,10 +97,10 @@ struct LBvhNode {              // 64 bytes
     uint32_t child[2];         // bit 31: leaf, bits 28..30: triangle count, low bits: first triangle; else node index
     uint32_t _pad[2];
 };
-struct LMeshTri {              // 112 bytes
-    double v1[3], v2[3], v3[3], n[3];
-    double inv_area;
-    double _pad;
+struct LMeshTri {              // 64 bytes: vertices as f32 (exact: only used when every coordinate is an f32 value,
+    float v1[3], v2[3], v3[3]; //           as it always is for OBJ input, mesh.rs:352-359), the unit normal as f64
+    float _pad;
+    double n[3];
 };
 
 struct DMesh {
@@ -138,8 +141,39 @@ struct DInstance {
     uint32_t prim, shader, node_id, is_root;
 };
 
+// Per-lane working memory of the trace kernel (global memory, one contiguous block per lane so
+// that a lane's 16-byte accesses stay within its own cache lines whatever its stack depth).
+struct alignas(16) LaneRay {   // one pending camera / secondary ray (Ray of src/geometry/ray.rs:4-9 plus its pixel weight)
+    double o[3], d[3];
+    double w[3];               // product of shader weights from the camera to this ray
+    double c[3];               // Ray::contribution
+    uint32_t depth, path;
+    uint32_t _pad[2];
+};
+struct alignas(16) ShadowJob { // a deferred point-light visibility test
+    double o[3], d[3];
+    double dist;               // distance to the light
+    double w[3];               // colour added to the sample if nothing blocks the light
+};
+struct alignas(16) TraceJob {  // one scene query of the current trip, between its phases
+    double t;                  // closest-hit: world distance of the best hit so far (+inf: none); any-hit: the distance limit
+    uint32_t inst;
+    uint32_t found;            // closest-hit: a hit exists; any-hit: an occluder was found
+    double ct;                 // candidate in the instance's primitive space (Cand)
+    uint32_t ca, cb;
+    uint32_t src;              // byte offset of the ray's o[3], d[3] in the lane's memory
+    uint32_t flags;            // bit 0: any-hit query; bit 1: nothing left to do (resolved, or never started)
+    uint32_t _pad[2];
+};
+#define RT_LANE_OFF_STACK 0u
+#define RT_LANE_OFF_JOBS (RT_LANE_OFF_STACK + RT_MAX_STACK * 112u)
+#define RT_LANE_OFF_SHADOW (RT_LANE_OFF_JOBS + (RT_BATCH + RT_MAX_SHADOW_JOBS) * 48u)
+#define RT_LANE_OFF_BVH (RT_LANE_OFF_SHADOW + RT_MAX_SHADOW_JOBS * 80u)
+#define RT_LANE_BYTES ((RT_LANE_OFF_BVH + (RT_BVH_STACK - RT_LDS_STACK) * 4u + 255u) & ~255u)
+
 struct DScene {
     const DInstance* instances;  uint32_t num_instances;
+    const uint32_t* mesh_instances; uint32_t num_mesh_instances;   // instances whose primitive is an un-wrapped mesh, ascending
     const DPrim* prims;
     const DTri* tris;
     const DPoly* polys;

@@ -110,6 +110,7 @@ inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 // ---- the flattened scene (host copies; uploaded verbatim) ----
 struct FlatScene {
     std::vector<DInstance> instances;
+    std::vector<uint32_t> mesh_instances;
     std::vector<DPrim> prims;
     std::vector<DTri> tris;
     std::vector<DPoly> polys;
@@ -137,6 +138,7 @@ struct FlatScene {
     uint32_t max_mesh_bvh_bytes = 0;
     uint32_t features = 0, max_ray_spawn = 0, max_shadow_spawn = 0, inline_point_lights = 0;
     std::vector<uint8_t> lds_blob;   // LBvhNode + LMeshTri arrays of all meshes
+    bool lds_exact = true;           // every mesh coordinate is an f32 value, so the f32 vertex copies lose nothing
 };
 
 // ---- BVH build: binned SAH, leaves of <= 4 triangles ----
@@ -303,8 +305,11 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
         for (uint32_t i = 0; i < dm.num_tris; ++i) {
             const DMeshTri& t = fs.mesh_tris[dm.tri_off + i];
             LMeshTri l{};
-            std::memcpy(l.v1, t.v1, sizeof l.v1); std::memcpy(l.v2, t.v2, sizeof l.v2); std::memcpy(l.v3, t.v3, sizeof l.v3);
-            std::memcpy(l.n, t.n, sizeof l.n); l.inv_area = t.inv_area;
+            for (int k = 0; k < 3; ++k) {
+                l.v1[k] = (float)t.v1[k]; l.v2[k] = (float)t.v2[k]; l.v3[k] = (float)t.v3[k];
+                if ((double)l.v1[k] != t.v1[k] || (double)l.v2[k] != t.v2[k] || (double)l.v3[k] != t.v3[k]) fs.lds_exact = false;
+            }
+            std::memcpy(l.n, t.n, sizeof l.n);
             const uint8_t* b = reinterpret_cast<const uint8_t*>(&l);
             fs.lds_blob.insert(fs.lds_blob.end(), b, b + sizeof l);
         }
@@ -430,6 +435,10 @@ private:
         }
         if (max_r + max_s > RT_SHADE_MAX_SPAWN) inline_points = true;
         if (inline_points) { f |= RTF_INLINE_LIGHTS; max_s = 0; }
+        for (uint32_t i = 0; i < fs_.instances.size(); ++i) {
+            const DPrim& p = fs_.prims[fs_.instances[i].prim];
+            if (p.kind == DP_MESH && !p.wrap) fs_.mesh_instances.push_back(i);
+        }
         fs_.features = f; fs_.max_ray_spawn = max_r; fs_.max_shadow_spawn = max_s; fs_.inline_point_lights = inline_points ? 1 : 0;
     }
 

@@ -5,10 +5,10 @@
 // thread pool (src/multithread.rs).
 //
 // k_trace is a persistent kernel.  Every lane owns one camera sample at a time and a
-// private stack of pending rays; each trip round the main loop pops ONE entry and runs
-// ONE scene query for it — closest hit for camera / reflected / refracted rays, any-hit
-// for the deferred point-light shadow tests — so all 64 lanes of a wave sit in the same
-// traversal code whatever kind of ray they carry.  A lane whose stack runs empty writes
+// private stack of pending rays (in its own block of global memory); each trip round the main loop pops a few entries and runs
+// the scene queries for them — closest hit for camera / reflected / refracted rays, any-hit
+// for the deferred point-light shadow tests — through the same code, so all 64 lanes of a
+// wave sit in the same traversal loop whatever kind of ray they carry.  A lane whose stack runs empty writes
 // its sample and immediately takes the next one from the wave's chunk of the global work
 // counter: cheap wall pixels (4 rays) and expensive glass pixels (hundreds) no longer
 // wait for each other inside a wave, which is what the reference's 500 dynamic row-chunks
@@ -16,14 +16,6 @@
 #pragma once
 #include "rt_shade.h"
 
-struct StackRay {         // one pending ray (Ray of src/geometry/ray.rs:4-9 plus its pixel weight)
-    d3 o, d;
-    d3 w;                 // RAY: product of shader weights from the camera to this ray; SHADOW: colour added if the light is visible
-    d3 c;                 // RAY: Ray::contribution; SHADOW: c.x = distance to the light
-    uint32_t depth;       // RAY: remaining depth; SHADOW: 0xFFFFFFFF
-    uint32_t path;
-};
-#define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
 // Load balancing across launches.  The cost of a camera sample is wildly uneven (a wall pixel
 // is 4 rays, a pixel through the glass mesh can be ten thousand, all serial in one lane), so a
@@ -124,6 +116,8 @@ struct TraceArgs {
     uint32_t mode;
     // rounds: round 0 takes its items from the image / the AA list, round r > 0 from in_items
     uint32_t round;
+    uint32_t batch;           // rays a lane takes off its stack per trip (<= RT_BATCH; 1 without meshes)
+    uint8_t* lane_mem;        // RT_LANE_BYTES per launched thread
     uint32_t budget;          // ray steps per item before its pending rays are handed to the next round
     const SpillItem* in_items;
     const unsigned int* in_count;
@@ -145,10 +139,11 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     if constexpr (F & RTF_LDS_BVH) {
         // stage every mesh's BVH nodes and triangles into LDS once per workgroup
         const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);
-        uint4* dst = reinterpret_cast<uint4*>(rt_lds_dynamic);
+        uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(rt_lds_base()));
         for (uint32_t i = threadIdx.x; i < sc.lds_blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
+    constexpr bool BATCHED = (F & RTF_MESH) != 0;    // scenes with meshes: several rays per trip, walked together
     const uint32_t W = rp.cam.width;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (W + 7) / 8;
@@ -159,10 +154,16 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
     const d3 cam_o = ld3(rp.cam.origin);
 
+    // this lane's working memory
+    uint8_t* lane_mem = a.lane_mem + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * RT_LANE_BYTES;
+    LaneRay* stack = reinterpret_cast<LaneRay*>(lane_mem + RT_LANE_OFF_STACK);
+    TraceJob* jobs = reinterpret_cast<TraceJob*>(lane_mem + RT_LANE_OFF_JOBS);
+    ShadowJob* shadows = reinterpret_cast<ShadowJob*>(lane_mem + RT_LANE_OFF_SHADOW);
+
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
-    StackRay stack[RT_MAX_STACK];
-    int sp = 0;
+    int sp = 0;                         // pending camera / secondary rays
+    uint32_t ns = 0;                    // pending shadow tests (spawned by the previous trip)
     // the sample this lane is working on
     bool active = false, exhausted = false, first = true;
     uint32_t item = 0;
@@ -178,7 +179,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
 
     for (;;) {
         // ---------------- finish / refill
-        if (active && sp == 0) {
+        if (active && sp == 0 && ns == 0) {
             if (acc_slot != RT_NO_SLOT) {
                 unsigned long long* limbs = a.acc + (size_t)acc_slot * RT_ACC_LIMBS;
                 acc_add(limbs, a.acc_flags + acc_slot, 0, color.x);
@@ -217,7 +218,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                 if (item >= total) {
                     exhausted = true;
                 } else {
-                    // ---- set up the camera sample
+                    // ---- set up the work item
                     d3 dir;
                     bool valid = true;
                     steps = 0;
@@ -230,9 +231,10 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                         else stream = rng_stream(rp.seed, a.list[it.out / rp.aa_rays], 1 + it.out % rp.aa_rays);
                         active = true; first = false; valid = false;
                         color = mk3(0.0, 0.0, 0.0);
-                        stack[0].o = ld3(it.o); stack[0].d = ld3(it.d); stack[0].w = ld3(it.w); stack[0].c = ld3(it.c);
-                        stack[0].depth = it.depth; stack[0].path = it.path;
-                        sp = 1;
+                        LaneRay& s0 = stack[0];
+                        for (int k = 0; k < 3; ++k) { s0.o[k] = it.o[k]; s0.d[k] = it.d[k]; s0.w[k] = it.w[k]; s0.c[k] = it.c[k]; }
+                        s0.depth = it.depth; s0.path = it.path;
+                        sp = 1; ns = 0;
                     } else if (a.mode == 0) {
                         uint32_t tile = item >> 6, within = item & 63u;
                         uint32_t x = (tile % tiles_x) * 8 + (within & 7u), ry = (tile / tiles_x) * 8 + (within >> 3);
@@ -259,10 +261,11 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                     if (valid) {
                         active = true; first = true; acc_slot = RT_NO_SLOT;
                         color = mk3(0.0, 0.0, 0.0); distance = INFINITY; hit_id = 0xFFFFFFFFu;
-                        stack[0].o = cam_o; stack[0].d = dir;
-                        stack[0].w = mk3(1.0, 1.0, 1.0); stack[0].c = mk3(1.0, 1.0, 1.0);
-                        stack[0].depth = rp.recursion_depth; stack[0].path = 1u;
-                        sp = 1;
+                        LaneRay& s0 = stack[0];
+                        st3(s0.o, cam_o); st3(s0.d, dir);
+                        st3(s0.w, mk3(1.0, 1.0, 1.0)); st3(s0.c, mk3(1.0, 1.0, 1.0));
+                        s0.depth = rp.recursion_depth; s0.path = 1u;
+                        sp = 1; ns = 0;
                     }
                 }
             }
@@ -270,73 +273,123 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         if (__ballot(active || !exhausted) == 0ull) break;
         if (!active) continue;
 
-        // ---------------- one ray
-        StackRay r = stack[--sp];
-        const bool shadow = r.depth == RT_SHADOW_ENTRY;
-        if (!shadow) {
-            // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
-            if (!(r.depth > 0 && (r.c.x + r.c.y + r.c.z) > RT_MIN_CONTRIBUTION)) {
-                color = color + r.w * background_color<F>(sc, r.d);
-                first = false;
-                continue;
-            }
-            if (steps >= a.budget) {
-                // out of budget: this ray and its whole subtree go to the next round
-                if (acc_slot == RT_NO_SLOT) {
-                    uint32_t slot = wave_alloc(a.acc_alloc);
-                    if (slot < a.acc_cap) { acc_slot = slot; a.acc_out[slot] = (uint32_t)out_index; }
+        // ---------------- one trip: the shadow tests spawned by the previous trip plus up to
+        // a.batch rays off the stack (they stay in their stack slots until phase B)
+        const bool primary_trip = first;
+        first = false;
+        const int sp0 = sp;
+        const uint32_t npop = min(a.batch, (uint32_t)sp);
+        const uint32_t njobs = ns + npop;
+        // phase A: gate, budget, every primitive except the un-wrapped meshes
+        for (uint32_t j = 0; j < njobs; ++j) {
+            TraceJob& q = jobs[j];
+            const bool shadow = j < ns;
+            d3 o, d;
+            double max_distance = 0.0;
+            if (shadow) {
+                const ShadowJob& s = shadows[j];
+                o = ld3(s.o); d = ld3(s.d); max_distance = s.dist;
+                q.src = RT_LANE_OFF_SHADOW + j * (uint32_t)sizeof(ShadowJob);
+                RT_COUNT(wk, rays_shadow);
+            } else {
+                const uint32_t slot = (uint32_t)sp0 - 1u - (j - ns);
+                const LaneRay& r = stack[slot];
+                o = ld3(r.o); d = ld3(r.d);
+                const d3 rc = ld3(r.c);
+                // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
+                if (!(r.depth > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
+                    color = color + ld3(r.w) * background_color<F>(sc, d);
+                    q.flags = 6u;                                   // resolved here, slot becomes free
+                    continue;
                 }
-                if (acc_slot != RT_NO_SLOT) {
-                    uint32_t q = wave_alloc(a.out_count);
-                    if (q < a.queue_cap) {
-                        SpillItem& it = a.out_items[q];
-                        it.o[0] = r.o.x; it.o[1] = r.o.y; it.o[2] = r.o.z;
-                        it.d[0] = r.d.x; it.d[1] = r.d.y; it.d[2] = r.d.z;
-                        it.w[0] = r.w.x; it.w[1] = r.w.y; it.w[2] = r.w.z;
-                        it.c[0] = r.c.x; it.c[1] = r.c.y; it.c[2] = r.c.z;
-                        it.depth = r.depth; it.path = r.path;
-                        it.out = (uint32_t)out_index; it.acc_slot = acc_slot;
-                        continue;
+                if (steps >= a.budget) {
+                    // out of budget: this ray and its whole subtree go to the next round
+                    if (acc_slot == RT_NO_SLOT) {
+                        uint32_t as = wave_alloc(a.acc_alloc);
+                        if (as < a.acc_cap) { acc_slot = as; a.acc_out[as] = (uint32_t)out_index; }
+                    }
+                    bool handed = false;
+                    if (acc_slot != RT_NO_SLOT) {
+                        uint32_t qi = wave_alloc(a.out_count);
+                        if (qi < a.queue_cap) {
+                            SpillItem& it = a.out_items[qi];
+                            for (int k = 0; k < 3; ++k) { it.o[k] = r.o[k]; it.d[k] = r.d[k]; it.w[k] = r.w[k]; it.c[k] = r.c[k]; }
+                            it.depth = r.depth; it.path = r.path;
+                            it.out = (uint32_t)out_index; it.acc_slot = acc_slot;
+                            handed = true;
+                        }
+                    }
+                    if (handed) { q.flags = 6u; continue; }
+                    // no room: trace it here after all
+                }
+                q.src = RT_LANE_OFF_STACK + slot * (uint32_t)sizeof(LaneRay);
+                if (COUNT) { if (primary_trip) cam++; else wk.rays_secondary++; }
+            }
+            ++steps;
+            SceneHit h;
+            h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
+            bool found = trace_scene<F, COUNT, BATCHED>(sc, o, d, shadow, max_distance, h, wk);
+            q.t = shadow ? max_distance : h.t;
+            q.inst = h.inst; q.found = found ? 1u : 0u;
+            q.ct = h.c.t; q.ca = h.c.a; q.cb = h.c.b;
+            q.flags = (shadow ? 1u : 0u) | ((shadow && found) ? 2u : 0u);   // an occluded shadow test is settled
+        }
+        // phase T: the meshes, for all of the trip's queries
+        if constexpr (BATCHED) mesh_walk_batch<(F & RTF_LDS_BVH) != 0, COUNT>(sc, lane_mem, jobs, njobs, wk);
+        // phase B: add the visible lights, shade the hits, push what they spawn
+        for (uint32_t j = 0; j < ns; ++j) {
+            if (!jobs[j].found) { color = color + ld3(shadows[j].w); RT_COUNT(wk, shade_evals); }
+        }
+        uint32_t ns_new = 0;
+        int top = sp0;
+        for (uint32_t k = 0; k < npop; ++k) {
+            const int slot = sp0 - 1 - (int)k;
+            const TraceJob q = jobs[ns + k];
+            bool reused = false;                                    // the slot holds a new ray
+            if (!(q.flags & 4u)) {
+                const LaneRay r = stack[slot];
+                const d3 rd = ld3(r.d), rw = ld3(r.w);
+                if (!q.found) {
+                    color = color + rw * background_color<F>(sc, rd);
+                } else {
+                    SceneHit h;
+                    h.t = q.t; h.inst = q.inst; h.c.t = q.ct; h.c.a = q.ca; h.c.b = q.cb;
+                    WorldHit wh;
+                    world_hit<F, COUNT>(sc, ld3(r.o), rd, h, wh, wk);
+                    const DInstance& in = sc.instances[h.inst];
+                    if (primary_trip) { distance = h.t; hit_id = in.node_id; }
+                    Spawn spawn[RT_SHADE_MAX_SPAWN];
+                    uint32_t nspawn;
+                    d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, spawn, nspawn, wk);
+                    color = color + rw * local;
+                    for (uint32_t i = 0; i < nspawn; ++i) {
+                        const Spawn& sn = spawn[i];
+                        if (sn.shadow) {
+                            if (ns_new >= RT_MAX_SHADOW_JOBS) { RT_COUNT(wk, stack_overflows); continue; }
+                            ShadowJob& s = shadows[ns_new++];
+                            st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w);
+                        } else {
+                            // the first new ray takes over its parent's slot, the others go on top
+                            int dst;
+                            if (!reused) { dst = slot; reused = true; }
+                            else {
+                                if (top >= RT_MAX_STACK) { RT_COUNT(wk, stack_overflows); continue; }
+                                dst = top++;
+                            }
+                            LaneRay& s = stack[dst];
+                            st3(s.o, sn.o); st3(s.d, sn.d); st3(s.w, rw * sn.w); st3(s.c, sn.c);
+                            s.depth = r.depth - 1; s.path = child_path(r.path, sn.ordinal);
+                        }
                     }
                 }
-                // no room: trace it here after all
             }
-            if (COUNT) { if (first) cam++; else wk.rays_secondary++; }
-        } else {
-            RT_COUNT(wk, rays_shadow);
-        }
-        ++steps;
-        SceneHit h;
-        bool found = trace_scene<F, COUNT>(sc, r.o, r.d, shadow, r.c.x, h, wk);
-        if (shadow) {
-            if (!found) { color = color + r.w; RT_COUNT(wk, shade_evals); }
-            continue;
-        }
-        const bool is_primary = first;
-        first = false;
-        if (!found) {
-            color = color + r.w * background_color<F>(sc, r.d);
-            continue;
-        }
-        WorldHit wh;
-        world_hit<F, COUNT>(sc, r.o, r.d, h, wh, wk);
-        const DInstance& in = sc.instances[h.inst];
-        if (is_primary) { distance = h.t; hit_id = in.node_id; }
-        Spawn spawn[RT_SHADE_MAX_SPAWN];
-        uint32_t nspawn;
-        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, r.d, r.c, stream, r.path, spawn, nspawn, wk);
-        color = color + r.w * local;
-        // secondary rays first, shadow tests on top so that they are resolved next
-        for (int pass = 0; pass < 2; ++pass)
-            for (uint32_t i = nspawn; i-- > 0;) {
-                if ((spawn[i].shadow != 0) != (pass == 1)) continue;
-                if (sp >= RT_MAX_STACK) { RT_COUNT(wk, stack_overflows); continue; }
-                StackRay& s = stack[sp++];
-                s.o = spawn[i].o; s.d = spawn[i].d;
-                s.w = r.w * spawn[i].w; s.c = spawn[i].c;
-                if (spawn[i].shadow) { s.depth = RT_SHADOW_ENTRY; s.path = 0; }
-                else { s.depth = r.depth - 1; s.path = child_path(r.path, spawn[i].ordinal); }
+            if (!reused) {                                          // free slot: the top entry moves down into it
+                --top;
+                if (slot != top) stack[slot] = stack[top];
             }
+        }
+        sp = top;
+        ns = ns_new;
     }
     if (a.mode == 0) flush_counters<COUNT>(a.counters, wk, cam, 0);
     else flush_counters<COUNT>(a.counters, wk, 0, cam);

@@ -12,6 +12,8 @@ struct d3 {
 };
 RT_DEV d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_DEV d3 ld3(const double* p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV d3 ld3(const float* p) { return mk3((double)p[0], (double)p[1], (double)p[2]); }
+RT_DEV void st3(double* p, d3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 RT_DEV d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_DEV d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV d3 operator*(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }

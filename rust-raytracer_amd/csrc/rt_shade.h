@@ -117,7 +117,7 @@ template <uint32_t F, bool COUNT>
 RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COUNT>& wk) {
     SceneHit h;
     RT_COUNT(wk, rays_shadow);
-    return trace_scene<F, COUNT>(sc, o, d, true, max_distance, h, wk);
+    return trace_scene<F, COUNT, false>(sc, o, d, true, max_distance, h, wk);
 }
 
 template <uint32_t F, bool COUNT>

@@ -16,8 +16,12 @@
 #define RT_MIN_CONTRIBUTION 0.003    // Ray::MIN_CONTRIBUTION, src/geometry/ray.rs:13
 #define RT_PI 3.14159265358979323846
 
+// Dynamic LDS of the trace kernel: [BVH walk stacks: RT_LDS_STACK rows of blockDim.x words][BVH blob].
 extern __shared__ __align__(16) uint8_t rt_lds_dynamic[];
-RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic; }
+RT_DEV uint32_t* rt_lds_stack() { return reinterpret_cast<uint32_t*>(rt_lds_dynamic); }
+RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic + (size_t)blockDim.x * RT_LDS_STACK * 4u; }
+
+#define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
 struct LRay {            // a ray in some local space, direction normalised (ray.rs:90-97)
     d3 o, d;
@@ -370,6 +374,142 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
     return found;
 }
 
+// The mesh part of all of a lane's queries of one trip in ONE loop.  A job is (query j of the
+// lane's table, mesh instance m); a lane whose job ends takes its next job without leaving
+// the loop, so the lanes of a wave run out of work together instead of each idling until the
+// slowest single walk is over.  Setting up a job (ray -> instance space, root box) is only
+// done when RT_REFILL_MIN lanes are waiting for it or nobody is walking any more.
+// The walk itself is mesh_walk's.  Results are merged into jobs[j]: the closest hit over the
+// instances already tested (ties go to the earlier instance, src/scene.rs:200-217), or the
+// any-hit verdict.  The walk stack lives in LDS (one column per thread), its overflow in the
+// lane's global memory.
+#define RT_REFILL_MIN 16
+template <bool LDS, bool COUNT>
+RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs, uint32_t njobs, Work<COUNT>& wk) {
+    const uint32_t nm = sc.num_mesh_instances;
+    uint32_t j = 0, m = 0;
+    while (j < njobs && (jobs[j].flags & 2u)) ++j;
+    bool more = j < njobs && nm > 0;
+    bool walking = false;
+    LRay lr; lr.o = mk3(0.0, 0.0, 0.0); lr.d = lr.o;
+    d3 inv = lr.o;
+    double best = 0.0, tmax = 0.0, inv_s = 1.0;
+    bool any = false, inclusive = false, found = false;
+    uint32_t tri = 0, inst = 0, cur = RT_WALK_DONE;
+    const DBvhNode* gnodes = sc.bvh_nodes;
+    const DMeshTri* gtris = sc.mesh_tris;
+    const LBvhNode* lnodes = reinterpret_cast<const LBvhNode*>(rt_lds_base());
+    const LMeshTri* ltris = reinterpret_cast<const LMeshTri*>(rt_lds_base());
+    uint32_t* lstack = rt_lds_stack() + threadIdx.x;
+    const uint32_t lstride = blockDim.x;
+    uint32_t* gstack = reinterpret_cast<uint32_t*>(lane_mem + RT_LANE_OFF_BVH);
+    int sp = 0;
+    auto push = [&](uint32_t v) {
+        if (sp < RT_LDS_STACK) lstack[sp * lstride] = v;
+        else if (sp < RT_BVH_STACK) gstack[sp - RT_LDS_STACK] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        if (sp == 0) return RT_WALK_DONE;
+        --sp;
+        return sp < RT_LDS_STACK ? lstack[sp * lstride] : gstack[sp - RT_LDS_STACK];
+    };
+    for (;;) {
+        const bool need = !walking && more;
+        const unsigned long long nmask = __ballot(need), wmask = __ballot(walking);
+        if (nmask == 0ull && wmask == 0ull) break;
+        if (nmask != 0ull && (wmask == 0ull || __popcll(nmask) >= RT_REFILL_MIN)) {
+            if (need) {
+                do {   // next job whose ray reaches the mesh's bounding box
+                    const TraceJob& q = jobs[j];
+                    const double* od = reinterpret_cast<const double*>(lane_mem + q.src);
+                    any = (q.flags & 1u) != 0;
+                    inst = sc.mesh_instances[m];
+                    const DInstance& in = sc.instances[inst];
+                    const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
+                    double s;
+                    lr = to_local(in.x, ld3(od), ld3(od + 3), s, inv_s);
+                    RT_COUNT(wk, instance_tests);
+                    inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+                    tmax = q.t * s;
+                    inclusive = in.is_root != 0;
+                    RT_COUNT(wk, box_tests);
+                    double tn;
+                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn)) {
+                        walking = true; cur = 0; sp = 0; found = false; best = tmax;
+                        gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
+                        lnodes = reinterpret_cast<const LBvhNode*>(rt_lds_base() + mesh.lds_node_off);
+                        ltris = reinterpret_cast<const LMeshTri*>(rt_lds_base() + mesh.lds_tri_off);
+                    } else {
+                        if (++m == nm) { m = 0; ++j; while (j < njobs && (jobs[j].flags & 2u)) ++j; }
+                        more = j < njobs;
+                    }
+                } while (!walking && more);
+            }
+        }
+        while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
+            double tn0, tn1;
+            bool h0, h1;
+            uint32_t c0, c1;
+            if (COUNT) wk.box_tests += 2;
+            if (LDS) {
+                const LBvhNode& n = lnodes[cur];
+                h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
+                h1 = slab_f32(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
+                c0 = n.child[0]; c1 = n.child[1];
+            } else {
+                const DBvhNode& n = gnodes[cur];
+                h0 = slab(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
+                h1 = slab(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
+                c0 = n.child[0]; c1 = n.child[1];
+            }
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                cur = swap ? c1 : c0;
+                push(swap ? c0 : c1);
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else cur = pop();
+        }
+        if (walking) {
+            if (cur != RT_WALK_DONE) {                                // the leaf's triangles
+                uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    double t;
+                    RT_COUNT(wk, tri_tests);
+                    bool hit = LDS ? mesh_tri_test(ltris[base + i], lr, t) : mesh_tri_test(gtris[base + i], lr, t);
+                    if (hit) {
+                        if (any) {
+                            if (inclusive ? t <= tmax : t < tmax) found = true;
+                        } else if (t < best) {
+                            best = t; tri = base + i; found = true;
+                        }
+                    }
+                }
+                cur = (any && found) ? RT_WALK_DONE : pop();
+            }
+            if (cur == RT_WALK_DONE) {                                // job over: merge, move on
+                TraceJob& q = jobs[j];
+                bool next_query = false;
+                if (found) {
+                    if (any) { q.found = 1u; next_query = true; }
+                    else {
+                        double tw = best * inv_s;
+                        if (tw < q.t || (tw == q.t && q.found && inst < q.inst)) {
+                            q.t = tw; q.inst = inst; q.found = 1u;
+                            q.ct = best; q.ca = tri; q.cb = 0u;
+                        }
+                    }
+                }
+                ++m;
+                if (next_query || m == nm) { m = 0; ++j; while (j < njobs && (jobs[j].flags & 2u)) ++j; }
+                more = j < njobs;
+                walking = false;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ basic (non-composite) primitives
 // get_all_intersects of a primitive without wrappers: up to two hits, ascending.
 template <uint32_t F, bool COUNT>
@@ -604,22 +744,25 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
 //                 all instances, strict '<', earlier instances (DFS pre-order) win ties;
 //   any == true:  SceneNode::partial_trace_until_distance (src/scene.rs:227-248) — does anything
 //                 lie closer than max_distance ('<=' for the root's own primitive, '<' below it)?
-template <uint32_t F, bool COUNT>
+// With SKIP_MESH the un-wrapped mesh instances are left out: the caller walks them for a
+// whole batch of rays at once (mesh_walk_batch) and merges the results.
+template <uint32_t F, bool COUNT, bool SKIP_MESH>
 RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk) {
     bool found = false;
     double best = any ? max_distance : INFINITY;
     for (uint32_t i = 0; i < sc.num_instances; ++i) {
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
+        if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) continue; }
         double s, inv_s;
         LRay lr = to_local(in.x, o, d, s, inv_s);
         RT_COUNT(wk, instance_tests);
         Cand c;
         bool got;
         bool direct_mesh = false;
-        if constexpr (F & RTF_MESH) direct_mesh = p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap);
+        if constexpr ((F & RTF_MESH) && !SKIP_MESH) direct_mesh = p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap);
         if (direct_mesh) {
-            if constexpr (F & RTF_MESH) {
+            if constexpr ((F & RTF_MESH) && !SKIP_MESH) {
                 // one call site for both query kinds: shadow lanes and camera/secondary lanes walk together
                 c.b = 0;
                 got = mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], lr, any, best * s, in.is_root != 0, c.t, c.a, wk);
