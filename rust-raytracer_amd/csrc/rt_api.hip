@@ -66,7 +66,7 @@ struct RtScene {
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
-    DeviceBuf queue[2], acc, acc_flags, acc_out, lane_mem;   // hand-over queues between rounds, split-sample accumulators
+    DeviceBuf queue[2], acc, acc_flags, lane_mem;   // hand-over queues between rounds, split-sample accumulators
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -94,7 +94,7 @@ void rt_scene_destroy(RtScene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
     for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
-                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->acc_out, &s->lane_mem}) b->release();
+                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->lane_mem}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -204,13 +204,14 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 constexpr uint32_t SC_AA_COUNT = 0, SC_ACC_ALLOC0 = 1, SC_ACC_ALLOC1 = 2;
 constexpr uint32_t SC_NEXT0 = 16, SC_NEXT1 = SC_NEXT0 + RT_MAX_ROUNDS + 1;          // work counters, one per round
 constexpr uint32_t SC_QUEUE0 = SC_NEXT1 + RT_MAX_ROUNDS + 1, SC_QUEUE1 = SC_QUEUE0 + RT_MAX_ROUNDS + 1;   // queue fill, one per round
-constexpr size_t SCALAR_BYTES = 1024;
-static_assert((SC_QUEUE1 + RT_MAX_ROUNDS + 1) * 4 <= SCALAR_BYTES, "scalar block too small");
-
-uint32_t trace_budget() {
-    static const uint32_t b = [] { const char* e = std::getenv("RT_TRACE_BUDGET"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 24u; }();
-    return b;
+constexpr uint32_t SC_IDLE0 = SC_QUEUE1 + RT_MAX_ROUNDS + 1, SC_IDLE1 = SC_IDLE0 + RT_MAX_ROUNDS + 1;      // idle lanes, one per round
+constexpr size_t SCALAR_BYTES = 2048;
+static_assert((SC_IDLE1 + RT_MAX_ROUNDS + 1) * 4 <= SCALAR_BYTES, "scalar block too small");
+uint32_t idle_divisor() {
+    static const uint32_t d = [] { const char* e = std::getenv("RT_IDLE_DIVISOR"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 8u; }();
+    return d;
 }
+
 uint32_t trace_rounds(uint32_t recursion_depth) {
     static const long forced = [] { const char* e = std::getenv("RT_TRACE_ROUNDS"); return e ? std::atol(e) : 0L; }();
     if (forced > 0) return (uint32_t)std::min<long>(forced, RT_MAX_ROUNDS);
@@ -284,15 +285,14 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     unsigned int* aa_count = scalars + SC_AA_COUNT;
     DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(s->scalars.p) + SCALAR_BYTES);
     HIP_TRY(hipMemsetAsync(s->scalars.p, 0, SCALAR_BYTES + sizeof(DCounters), stream));
-    // hand-over queues and accumulators for samples split across rounds
-    const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 16), 1u << 25);
-    const uint32_t acc_cap = (uint32_t)std::min<size_t>(npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u), 1u << 23);
-    for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(SpillItem))) != RT_OK) return e;
+    // hand-over queues between rounds, one accumulator per sample slot
+    const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 22), 1u << 25);
+    const size_t acc_slots = npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u);
+    for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
     {
-        bool fresh = s->acc.bytes < (size_t)acc_cap * RT_ACC_LIMBS * 8;
-        if ((e = s->acc.ensure((size_t)acc_cap * RT_ACC_LIMBS * 8)) != RT_OK) return e;
-        if ((e = s->acc_flags.ensure((size_t)acc_cap * 4)) != RT_OK) return e;
-        if ((e = s->acc_out.ensure((size_t)acc_cap * 4)) != RT_OK) return e;
+        bool fresh = s->acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
+        if ((e = s->acc.ensure(acc_slots * RT_ACC_LIMBS * 8)) != RT_OK) return e;
+        if ((e = s->acc_flags.ensure(acc_slots * 4)) != RT_OK) return e;
         if (fresh || s->acc_dirty) {
             HIP_TRY(hipMemsetAsync(s->acc.p, 0, s->acc.bytes, stream));
             HIP_TRY(hipMemsetAsync(s->acc_flags.p, 0, s->acc_flags.bytes, stream));
@@ -300,8 +300,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         s->acc_dirty = true;
     }
     HIP_TRY(hipMemsetAsync(s->mask.p, 0, npix, stream));
-    if (rp.nranks > 1) {   // rows never rendered by this rank must not look like data
-        HIP_TRY(hipMemsetAsync(s->color.p, 0, npix * 3 * sizeof(double), stream));
+    if (rp.nranks > 1) {   // rows never rendered by this rank must not look like data (their colour resolves to 0)
         HIP_TRY(hipMemsetAsync(s->distance.p, 0, npix * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(s->hit_id.p, 0xFF, npix * sizeof(uint32_t), stream));
     }
@@ -322,32 +321,34 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     }
     TraceArgs ta{};
     ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
-    ta.color = (double*)s->color.p; ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
-    ta.list = nullptr; ta.count = aa_count; ta.samples = nullptr; ta.counters = counters; ta.mode = 0;
+    ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
+    ta.list = nullptr; ta.count = aa_count; ta.counters = counters; ta.mode = 0;
     ta.batch = batch; ta.lane_mem = (uint8_t*)s->lane_mem.p;
     ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)s->acc.p; ta.acc_flags = (uint32_t*)s->acc_flags.p;
-    ta.acc_out = (uint32_t*)s->acc_out.p; ta.acc_cap = acc_cap;
-    // Rounds: every round but the last hands rays on once an item has used its budget; a chain of
-    // secondary rays advances at least one level per round, so recursion_depth + 1 rounds reach
-    // every ray and the unbudgeted last round only sees leftovers.  Rounds with an empty queue
-    // return at once.
+    // Rounds: a launch ends once its work has all been dealt out, and what the lanes still hold is
+    // dealt out again by the next one.  A ray handed on is traced in the next round, so a chain of
+    // secondary rays advances at least one level per round: recursion_depth + 1 rounds reach every
+    // ray, and the last round runs to completion in any case.  Rounds with an empty queue return at once.
     const uint32_t rounds = trace_rounds(rc.recursion_depth);
     auto run_rounds = [&](uint32_t mode, uint32_t first_grid, double* dst) -> int {
         ta.mode = mode;
-        ta.acc_alloc = scalars + (mode == 0 ? SC_ACC_ALLOC0 : SC_ACC_ALLOC1);
         for (uint32_t r = 0; r < rounds; ++r) {
             ta.round = r;
-            ta.budget = r + 1 < rounds ? trace_budget() : 0xFFFFFFFFu;
+            ta.last_round = r + 1 == rounds ? 1u : 0u;
             ta.next_item = scalars + (mode == 0 ? SC_NEXT0 : SC_NEXT1) + r;
-            ta.in_items = (const SpillItem*)s->queue[r & 1].p;
+            ta.idle_count = scalars + (mode == 0 ? SC_IDLE0 : SC_IDLE1) + r;
+            ta.idle_limit = std::max(1u, (r == 0 ? first_grid : max_waves) * 64u / idle_divisor());
+            ta.in_items = (const LaneRay*)s->queue[r & 1].p;
             ta.in_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r;
-            ta.out_items = (SpillItem*)s->queue[(r + 1) & 1].p;
+            ta.out_items = (LaneRay*)s->queue[(r + 1) & 1].p;
             ta.out_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r + 1;
             int lrc = launch_trace(s->ds.features, count_work, r == 0 ? first_grid : max_waves, stream, s->ds, rp, ta);
             if (lrc != RT_OK) return lrc;
         }
-        hipLaunchKernelGGL(k_acc_resolve, dim3(1024), dim3(256), 0, stream, ta.acc, ta.acc_flags, (const uint32_t*)ta.acc_out,
-                           (const unsigned int*)ta.acc_alloc, acc_cap, dst);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, ta.acc, ta.acc_flags, (const unsigned int*)nullptr, 0u, (uint32_t)npix, dst);
+        else
+            hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, ta.acc, ta.acc_flags, (const unsigned int*)aa_count, rc.aa_rays, 0u, dst);
         HIP_TRY(hipGetLastError());
         return RT_OK;
     };
@@ -365,7 +366,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, (const double*)s->distance.p,
                            (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
         HIP_TRY(hipGetLastError());
-        ta.list = (const uint32_t*)s->list.p; ta.samples = (double*)s->samples.p;
+        ta.list = (const uint32_t*)s->list.p;
         int lrc = run_rounds(1, max_waves, (double*)s->samples.p);
         if (lrc != RT_OK) return lrc;
         hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
@@ -482,7 +483,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];
             HIP_TRY(hipMemcpy(sc, s->scalars.p, SCALAR_BYTES, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[rt] split samples: pass1 %u aa %u\n[rt] queue pass1:", sc[SC_ACC_ALLOC0], sc[SC_ACC_ALLOC1]);
+            std::fprintf(stderr, "[rt] queue pass1:");
             for (uint32_t r = 1; r <= RT_MAX_ROUNDS && sc[SC_QUEUE0 + r]; ++r) std::fprintf(stderr, " %u", sc[SC_QUEUE0 + r]);
             std::fprintf(stderr, "\n[rt] queue aa:");
             for (uint32_t r = 1; r <= RT_MAX_ROUNDS && sc[SC_QUEUE1 + r]; ++r) std::fprintf(stderr, " %u", sc[SC_QUEUE1 + r]);

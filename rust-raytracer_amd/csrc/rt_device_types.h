@@ -148,12 +148,15 @@ struct alignas(16) LaneRay {   // one pending camera / secondary ray (Ray of src
     double w[3];               // product of shader weights from the camera to this ray
     double c[3];               // Ray::contribution
     uint32_t depth, path;
-    uint32_t _pad[2];
+    uint32_t slot;             // the sample it belongs to: pixel index (pass 1) or AA sample index; also its accumulator
+    uint32_t flags;            // bit 0: pass-1 camera ray (its hit is the pixel's distance / hit id); bit 1: camera ray of either pass
 };
 struct alignas(16) ShadowJob { // a deferred point-light visibility test
     double o[3], d[3];
     double dist;               // distance to the light
     double w[3];               // colour added to the sample if nothing blocks the light
+    uint32_t slot;
+    uint32_t _pad[3];
 };
 struct alignas(16) TraceJob {  // one scene query of the current trip, between its phases
     double t;                  // closest-hit: world distance of the best hit so far (+inf: none); any-hit: the distance limit
@@ -168,7 +171,7 @@ struct alignas(16) TraceJob {  // one scene query of the current trip, between i
 #define RT_LANE_OFF_STACK 0u
 #define RT_LANE_OFF_JOBS (RT_LANE_OFF_STACK + RT_MAX_STACK * 112u)
 #define RT_LANE_OFF_SHADOW (RT_LANE_OFF_JOBS + (RT_BATCH + RT_MAX_SHADOW_JOBS) * 48u)
-#define RT_LANE_OFF_BVH (RT_LANE_OFF_SHADOW + RT_MAX_SHADOW_JOBS * 80u)
+#define RT_LANE_OFF_BVH (RT_LANE_OFF_SHADOW + RT_MAX_SHADOW_JOBS * 96u)
 #define RT_LANE_BYTES ((RT_LANE_OFF_BVH + (RT_BVH_STACK - RT_LDS_STACK) * 4u + 255u) & ~255u)
 
 struct DScene {

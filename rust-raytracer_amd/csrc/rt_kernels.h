@@ -4,34 +4,30 @@
 // Frame driver they replace: render_with_config (src/render.rs:99-312) with its
 // thread pool (src/multithread.rs).
 //
-// k_trace is a persistent kernel.  Every lane owns one camera sample at a time and a
-// private stack of pending rays (in its own block of global memory); each trip round the main loop pops a few entries and runs
-// the scene queries for them — closest hit for camera / reflected / refracted rays, any-hit
-// for the deferred point-light shadow tests — through the same code, so all 64 lanes of a
-// wave sit in the same traversal loop whatever kind of ray they carry.  A lane whose stack runs empty writes
-// its sample and immediately takes the next one from the wave's chunk of the global work
-// counter: cheap wall pixels (4 rays) and expensive glass pixels (hundreds) no longer
-// wait for each other inside a wave, which is what the reference's 500 dynamic row-chunks
-// achieve for CPU threads.
+// k_trace is a persistent kernel of ray processors.  Every lane keeps a private stack of
+// pending rays (in its own block of global memory) and, whenever the stack runs low, takes
+// more work from a global counter: a pixel or AA sample (round 0), or a ray another lane
+// handed on (later rounds).  The rays on a lane's stack may belong to different samples;
+// each carries the slot of its sample, and every colour contribution is added to that
+// slot's fixed-point accumulator (integer adds commute, so the image does not depend on
+// which lane traced what or in which order; k_acc_resolve turns the sums into f64).
+//
+// Each trip round the main loop takes a few rays off the stack plus the shadow tests
+// the previous trip's hits asked for, and runs them through three phases shared by all 64
+// lanes: (A) the analytic primitives, (T) the mesh BVH walk for all of the trip's queries
+// in one loop, (B) shading, which pushes the reflected / refracted rays and queues the
+// next shadow tests.
+//
+// Load balancing across launches ("rounds").  The cost of a sample is wildly uneven (a wall
+// pixel is 4 rays, a pixel through the glass mesh can be ten thousand), so one launch does
+// not run every sample to completion: as soon as the launch's work counter is exhausted
+// every lane finishes the trip it is in and writes what is left on its stack to a queue;
+// the next launch deals those rays out again over all lanes.  A ray handed on is always
+// traced in the next round, so recursion_depth + 1 rounds finish every sample; the last
+// round runs to completion regardless.
 #pragma once
 #include "rt_shade.h"
 
-
-// Load balancing across launches.  The cost of a camera sample is wildly uneven (a wall pixel
-// is 4 rays, a pixel through the glass mesh can be ten thousand, all serial in one lane), so a
-// launch gives every work item a budget of ray steps.  Once the budget is used up the lane stops
-// tracing camera/secondary rays of that item: each one still pending on its stack is written to
-// a queue in global memory and becomes a work item of its own in the next launch ("round").
-// Every part of a split sample adds its share of the colour into a fixed-point accumulator
-// (integer adds commute, so the sum does not depend on the order in which lanes finish);
-// k_acc_resolve turns the accumulators back into f64.
-struct SpillItem {        // 112 bytes
-    double o[3], d[3], w[3], c[3];
-    uint32_t depth, path;
-    uint32_t out;         // output slot: pixel index (pass 1) or sample index (AA resolve)
-    uint32_t acc_slot;
-};
-#define RT_NO_SLOT 0xFFFFFFFFu
 #define RT_ACC_LIMBS 9    // 3 channels x 3 signed limbs of weight 2^0, 2^-40, 2^-80
 
 // One unique index per calling lane from a shared counter, one atomic per wave.
@@ -45,22 +41,42 @@ RT_DEV uint32_t wave_alloc(unsigned int* counter) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// Adds v into three signed 64-bit limbs (exact for |v| in [2^-27, 2^40); smaller parts are cut
-// at 2^-80).  Non-finite and absurdly large values are recorded as flags instead.
-RT_DEV void acc_add(unsigned long long* limbs, uint32_t* flags, uint32_t channel, double v) {
+// A lane's pending contributions to one sample: per channel three integer-valued doubles
+// (limbs of weight 2^0, 2^-40, 2^-80).  Splitting a colour into limbs is exact for |v| in
+// [2^-27, 2^40) (smaller parts are cut at 2^-80); limb sums stay exact in f64 as long as fewer
+// than 2^12 terms are pending, so they are flushed to the global 64-bit integer accumulators
+// before that.  Non-finite and absurdly large values are recorded as flags instead.
+struct LaneAcc {
+    uint32_t slot, terms, flags;
+    double l[RT_ACC_LIMBS];
+};
+#define RT_NO_SLOT 0xFFFFFFFFu
+RT_DEV void acc_flush(LaneAcc& la, unsigned long long* acc, uint32_t* acc_flags) {
+    if (la.slot != RT_NO_SLOT) {
+        unsigned long long* limbs = acc + (size_t)la.slot * RT_ACC_LIMBS;
+        for (int i = 0; i < RT_ACC_LIMBS; ++i)
+            if (la.l[i] != 0.0) atomicAdd(limbs + i, (unsigned long long)(long long)la.l[i]);
+        if (la.flags) atomicOr(acc_flags + la.slot, la.flags);
+    }
+    for (int i = 0; i < RT_ACC_LIMBS; ++i) la.l[i] = 0.0;
+    la.terms = 0; la.flags = 0; la.slot = RT_NO_SLOT;
+}
+RT_DEV void acc_term(LaneAcc& la, int channel, double v) {
     if (!(fabs(v) < 0x1p40)) {
         uint32_t bit = (v != v) ? 4u : (v > 0.0 ? 1u : 2u);
-        atomicOr(flags, bit << (3u * channel));
+        la.flags |= bit << (3 * channel);
         return;
     }
     double l0 = trunc(v);
     double r1 = (v - l0) * 0x1p40;
     double l1 = trunc(r1);
     double l2 = trunc((r1 - l1) * 0x1p40);
-    unsigned long long* a = limbs + 3u * channel;
-    if (l0 != 0.0) atomicAdd(a, (unsigned long long)(long long)l0);
-    if (l1 != 0.0) atomicAdd(a + 1, (unsigned long long)(long long)l1);
-    if (l2 != 0.0) atomicAdd(a + 2, (unsigned long long)(long long)l2);
+    la.l[3 * channel] += l0; la.l[3 * channel + 1] += l1; la.l[3 * channel + 2] += l2;
+}
+RT_DEV void acc_contribute(LaneAcc& la, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags) {
+    if (la.slot != slot || la.terms >= 4000u) { acc_flush(la, acc, acc_flags); la.slot = slot; }
+    la.terms++;
+    acc_term(la, 0, c.x); acc_term(la, 1, c.y); acc_term(la, 2, c.z);
 }
 RT_DEV double acc_value(const unsigned long long* limbs, uint32_t flags, uint32_t channel) {
     uint32_t f = (flags >> (3u * channel)) & 7u;
@@ -104,31 +120,28 @@ struct TraceArgs {
     // one-row halo the AA stencil needs); work items are pixels in 8x8 tiles over (width x num_rows)
     const uint32_t* rows;
     uint32_t num_rows;
-    double* color;            // W*H*3
     double* distance;         // W*H
     uint32_t* hit_id;         // W*H
     // AA resolve (mode 1): one work item per (flagged pixel, extra ray), src/render.rs:259-299
     const uint32_t* list;
     const unsigned int* count;
-    double* samples;          // count*aa_rays*3
     unsigned int* next_item;  // global work counter
     DCounters* counters;
     uint32_t mode;
     // rounds: round 0 takes its items from the image / the AA list, round r > 0 from in_items
     uint32_t round;
+    uint32_t last_round;      // 1: run every ray to completion, hand nothing on
+    unsigned int* idle_count; // lanes of this launch that have run out of work
+    uint32_t idle_limit;      // ... and how many of them end the round
     uint32_t batch;           // rays a lane takes off its stack per trip (<= RT_BATCH; 1 without meshes)
     uint8_t* lane_mem;        // RT_LANE_BYTES per launched thread
-    uint32_t budget;          // ray steps per item before its pending rays are handed to the next round
-    const SpillItem* in_items;
+    const LaneRay* in_items;
     const unsigned int* in_count;
-    SpillItem* out_items;
+    LaneRay* out_items;
     unsigned int* out_count;
     uint32_t queue_cap;
-    unsigned long long* acc;  // acc_cap x RT_ACC_LIMBS, all zero between frames
-    uint32_t* acc_flags;      // acc_cap
-    uint32_t* acc_out;        // acc_cap: output slot of each accumulator
-    unsigned int* acc_alloc;
-    uint32_t acc_cap;
+    unsigned long long* acc;  // one accumulator (RT_ACC_LIMBS words) per sample slot, all zero between frames
+    uint32_t* acc_flags;
 };
 
 template <uint32_t F, bool COUNT>
@@ -144,6 +157,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         __syncthreads();
     }
     constexpr bool BATCHED = (F & RTF_MESH) != 0;    // scenes with meshes: several rays per trip, walked together
+    constexpr int KB = BATCHED ? RT_BATCH : 1;
     const uint32_t W = rp.cam.width;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (W + 7) / 8;
@@ -164,41 +178,28 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     unsigned long long cam = 0;
     int sp = 0;                         // pending camera / secondary rays
     uint32_t ns = 0;                    // pending shadow tests (spawned by the previous trip)
-    // the sample this lane is working on
-    bool active = false, exhausted = false, first = true;
-    uint32_t item = 0;
-    uint32_t steps = 0;                 // ray steps spent on the current item
-    uint32_t acc_slot = RT_NO_SLOT;     // accumulator of the current item's sample once it has been split
-    size_t out_index = 0;
-    uint64_t stream = 0;
-    d3 color = mk3(0.0, 0.0, 0.0);
-    double distance = INFINITY;
-    uint32_t hit_id = 0xFFFFFFFFu;
+    bool exhausted = false;             // this lane asked for work and there was none left
+    bool draining = false;              // enough lanes are idle: finish this trip, hand the rest on
+    bool idle_counted = false;
+    LaneAcc la;
+    la.slot = RT_NO_SLOT; la.terms = 0; la.flags = 0;
+    for (int i = 0; i < RT_ACC_LIMBS; ++i) la.l[i] = 0.0;
     // the wave's reserved chunk of the work counter (wave-uniform)
     uint32_t chunk_next = 0, chunk_end = 0;
 
+    auto hand_on = [&](const LaneRay& r) -> bool {                 // write a ray to the next round's queue
+        uint32_t qi = wave_alloc(a.out_count);
+        if (qi >= a.queue_cap) return false;
+        a.out_items[qi] = r;
+        return true;
+    };
+
     for (;;) {
-        // ---------------- finish / refill
-        if (active && sp == 0 && ns == 0) {
-            if (acc_slot != RT_NO_SLOT) {
-                unsigned long long* limbs = a.acc + (size_t)acc_slot * RT_ACC_LIMBS;
-                acc_add(limbs, a.acc_flags + acc_slot, 0, color.x);
-                acc_add(limbs, a.acc_flags + acc_slot, 1, color.y);
-                acc_add(limbs, a.acc_flags + acc_slot, 2, color.z);
-            } else if (a.mode == 0) {
-                a.color[3 * out_index] = color.x; a.color[3 * out_index + 1] = color.y; a.color[3 * out_index + 2] = color.z;
-            } else {
-                a.samples[3 * out_index] = color.x; a.samples[3 * out_index + 1] = color.y; a.samples[3 * out_index + 2] = color.z;
-            }
-            if (a.mode == 0 && a.round == 0) {
-                a.distance[out_index] = distance;
-                a.hit_id[out_index] = hit_id;
-            }
-            active = false;
-        }
-        bool need = !active && !exhausted;
-        unsigned long long needy = __ballot(need);
-        if (needy) {
+        // ---------------- take work until a.batch rays are pending
+        auto take = [&](bool need) {                                // one item for every lane that asks
+            unsigned long long needy = __ballot(need);
+            if (!needy) return false;
+            uint32_t item = 0;
             uint32_t want = (uint32_t)__popcll(needy);
             uint32_t rank = (uint32_t)__popcll(needy & ((1ull << lane) - 1ull));
             uint32_t avail = chunk_end - chunk_next;
@@ -214,73 +215,76 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                 if (need) item = chunk_next + rank;
                 chunk_next += want;
             }
-            if (need) {
-                if (item >= total) {
-                    exhausted = true;
-                } else {
-                    // ---- set up the work item
-                    d3 dir;
-                    bool valid = true;
-                    steps = 0;
-                    if (a.round > 0) {
-                        // a ray handed on by the previous round: a work item of its own
-                        const SpillItem& it = a.in_items[item];
-                        out_index = it.out;
-                        acc_slot = it.acc_slot;
-                        if (a.mode == 0) stream = rng_stream(rp.seed, out_index, 0);
-                        else stream = rng_stream(rp.seed, a.list[it.out / rp.aa_rays], 1 + it.out % rp.aa_rays);
-                        active = true; first = false; valid = false;
-                        color = mk3(0.0, 0.0, 0.0);
-                        LaneRay& s0 = stack[0];
-                        for (int k = 0; k < 3; ++k) { s0.o[k] = it.o[k]; s0.d[k] = it.d[k]; s0.w[k] = it.w[k]; s0.c[k] = it.c[k]; }
-                        s0.depth = it.depth; s0.path = it.path;
-                        sp = 1; ns = 0;
-                    } else if (a.mode == 0) {
-                        uint32_t tile = item >> 6, within = item & 63u;
-                        uint32_t x = (tile % tiles_x) * 8 + (within & 7u), ry = (tile / tiles_x) * 8 + (within >> 3);
-                        if (x >= W || ry >= a.num_rows) valid = false;
-                        else {
-                            uint32_t y = a.rows[ry];
-                            out_index = (size_t)y * W + x;
-                            dir = camera_dir(rp.cam, (double)x + 0.5, (double)y + 0.5);      // render.rs:167
-                            stream = rng_stream(rp.seed, out_index, 0);
-                        }
-                    } else {
-                        uint32_t f = item / rp.aa_rays, i = item % rp.aa_rays;
-                        uint32_t pixel = a.list[f];
-                        uint32_t x = pixel % W, y = pixel / W;
-                        uint64_t stream0 = rng_stream(rp.seed, pixel, 0);
-                        double rand_rotation = 0.0 + (2.0 * RT_PI - 0.0) * rng_aa(stream0, 0);   // render.rs:266
-                        double ax = cos(rand_rotation + theta * (double)i);
-                        double ay = sin(rand_rotation + theta * (double)i);
-                        double rand_distance = 0.2 + (0.5 - 0.2) * rng_aa(stream0, 1 + i);       // render.rs:277
-                        dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
-                        stream = rng_stream(rp.seed, pixel, 1 + i);
-                        out_index = item;
-                    }
-                    if (valid) {
-                        active = true; first = true; acc_slot = RT_NO_SLOT;
-                        color = mk3(0.0, 0.0, 0.0); distance = INFINITY; hit_id = 0xFFFFFFFFu;
-                        LaneRay& s0 = stack[0];
-                        st3(s0.o, cam_o); st3(s0.d, dir);
-                        st3(s0.w, mk3(1.0, 1.0, 1.0)); st3(s0.c, mk3(1.0, 1.0, 1.0));
-                        s0.depth = rp.recursion_depth; s0.path = 1u;
-                        sp = 1; ns = 0;
-                    }
+            if (!need) return true;
+            if (item >= total) { exhausted = true; return true; }
+            LaneRay& s0 = stack[sp];
+            if (a.round > 0) {
+                s0 = a.in_items[item];                                 // a ray handed on by the previous round
+                ++sp;
+                return true;
+            }
+            d3 dir;
+            uint32_t slot;
+            if (a.mode == 0) {
+                uint32_t tile = item >> 6, within = item & 63u;
+                uint32_t x = (tile % tiles_x) * 8 + (within & 7u), ry = (tile / tiles_x) * 8 + (within >> 3);
+                if (x >= W || ry >= a.num_rows) return true;
+                uint32_t y = a.rows[ry];
+                slot = y * W + x;
+                dir = camera_dir(rp.cam, (double)x + 0.5, (double)y + 0.5);              // render.rs:167
+            } else {
+                uint32_t fi = item / rp.aa_rays, i = item % rp.aa_rays;
+                uint32_t pixel = a.list[fi];
+                uint32_t x = pixel % W, y = pixel / W;
+                uint64_t stream0 = rng_stream(rp.seed, pixel, 0);
+                double rand_rotation = 0.0 + (2.0 * RT_PI - 0.0) * rng_aa(stream0, 0);       // render.rs:266
+                double ax = cos(rand_rotation + theta * (double)i);
+                double ay = sin(rand_rotation + theta * (double)i);
+                double rand_distance = 0.2 + (0.5 - 0.2) * rng_aa(stream0, 1 + i);           // render.rs:277
+                dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
+                slot = item;
+            }
+            st3(s0.o, cam_o); st3(s0.d, dir);
+            st3(s0.w, mk3(1.0, 1.0, 1.0)); st3(s0.c, mk3(1.0, 1.0, 1.0));
+            s0.depth = rp.recursion_depth; s0.path = 1u; s0.slot = slot; s0.flags = a.mode == 0 ? 3u : 2u;
+            ++sp;
+            return true;
+        };
+        if (!draining) {
+            for (int f = 0; f < KB; ++f)
+                if (!take((uint32_t)sp < a.batch && !exhausted)) break;
+            // Once enough lanes of the launch have run out of work, the others stop after the trip
+            // they are in and hand their rays on, so that the next round can deal them out evenly.
+            if (!a.last_round) {
+                const bool now_idle = exhausted && sp == 0 && ns == 0 && !idle_counted;
+                const unsigned long long im = __ballot(now_idle);
+                if (im && lane == (uint32_t)(__ffsll((long long)im) - 1)) atomicAdd(a.idle_count, (unsigned int)__popcll(im));
+                if (now_idle) idle_counted = true;
+                if (__hip_atomic_load(a.idle_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.idle_limit) {
+                    draining = true;
+                    // items this wave had reserved but not yet taken must not get lost (wave-uniform test)
+                    if (chunk_next < chunk_end && chunk_next < total && sp < RT_MAX_STACK) take(!exhausted);
                 }
             }
         }
-        if (__ballot(active || !exhausted) == 0ull) break;
-        if (!active) continue;
+        if (__ballot(sp > 0 || ns > 0 || !(exhausted || draining)) == 0ull) break;
+        if (sp == 0 && ns == 0) continue;
 
         // ---------------- one trip: the shadow tests spawned by the previous trip plus up to
         // a.batch rays off the stack (they stay in their stack slots until phase B)
-        const bool primary_trip = first;
-        first = false;
-        const int sp0 = sp;
         const uint32_t npop = min(a.batch, (uint32_t)sp);
+        if (draining) {
+            // everything below the rays of this trip goes to the next round now
+            int keep = 0;
+            for (int i = 0; i < sp - (int)npop; ++i) {
+                if (!hand_on(stack[i])) { if (keep != i) stack[keep] = stack[i]; ++keep; }
+            }
+            if (keep != sp - (int)npop) for (uint32_t k = 0; k < npop; ++k) stack[keep + k] = stack[sp - (int)npop + k];
+            sp = keep + (int)npop;
+        }
+        const int sp0 = sp;
         const uint32_t njobs = ns + npop;
-        // phase A: gate, budget, every primitive except the un-wrapped meshes
+        // phase A: gate, every primitive except the un-wrapped meshes
         for (uint32_t j = 0; j < njobs; ++j) {
             TraceJob& q = jobs[j];
             const bool shadow = j < ns;
@@ -298,34 +302,14 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                 const d3 rc = ld3(r.c);
                 // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
                 if (!(r.depth > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
-                    color = color + ld3(r.w) * background_color<F>(sc, d);
+                    acc_contribute(la, r.slot, ld3(r.w) * background_color<F>(sc, d), a.acc, a.acc_flags);
+                    if (r.flags & 1u) { a.distance[r.slot] = INFINITY; a.hit_id[r.slot] = 0xFFFFFFFFu; }
                     q.flags = 6u;                                   // resolved here, slot becomes free
                     continue;
                 }
-                if (steps >= a.budget) {
-                    // out of budget: this ray and its whole subtree go to the next round
-                    if (acc_slot == RT_NO_SLOT) {
-                        uint32_t as = wave_alloc(a.acc_alloc);
-                        if (as < a.acc_cap) { acc_slot = as; a.acc_out[as] = (uint32_t)out_index; }
-                    }
-                    bool handed = false;
-                    if (acc_slot != RT_NO_SLOT) {
-                        uint32_t qi = wave_alloc(a.out_count);
-                        if (qi < a.queue_cap) {
-                            SpillItem& it = a.out_items[qi];
-                            for (int k = 0; k < 3; ++k) { it.o[k] = r.o[k]; it.d[k] = r.d[k]; it.w[k] = r.w[k]; it.c[k] = r.c[k]; }
-                            it.depth = r.depth; it.path = r.path;
-                            it.out = (uint32_t)out_index; it.acc_slot = acc_slot;
-                            handed = true;
-                        }
-                    }
-                    if (handed) { q.flags = 6u; continue; }
-                    // no room: trace it here after all
-                }
                 q.src = RT_LANE_OFF_STACK + slot * (uint32_t)sizeof(LaneRay);
-                if (COUNT) { if (primary_trip) cam++; else wk.rays_secondary++; }
+                if (COUNT) { if (r.flags & 2u) cam++; else wk.rays_secondary++; }
             }
-            ++steps;
             SceneHit h;
             h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
             bool found = trace_scene<F, COUNT, BATCHED>(sc, o, d, shadow, max_distance, h, wk);
@@ -338,7 +322,10 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         if constexpr (BATCHED) mesh_walk_batch<(F & RTF_LDS_BVH) != 0, COUNT>(sc, lane_mem, jobs, njobs, wk);
         // phase B: add the visible lights, shade the hits, push what they spawn
         for (uint32_t j = 0; j < ns; ++j) {
-            if (!jobs[j].found) { color = color + ld3(shadows[j].w); RT_COUNT(wk, shade_evals); }
+            if (!jobs[j].found) {
+                acc_contribute(la, shadows[j].slot, ld3(shadows[j].w), a.acc, a.acc_flags);
+                RT_COUNT(wk, shade_evals);
+            }
         }
         uint32_t ns_new = 0;
         int top = sp0;
@@ -350,35 +337,38 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                 const LaneRay r = stack[slot];
                 const d3 rd = ld3(r.d), rw = ld3(r.w);
                 if (!q.found) {
-                    color = color + rw * background_color<F>(sc, rd);
+                    acc_contribute(la, r.slot, rw * background_color<F>(sc, rd), a.acc, a.acc_flags);
+                    if (r.flags & 1u) { a.distance[r.slot] = INFINITY; a.hit_id[r.slot] = 0xFFFFFFFFu; }
                 } else {
                     SceneHit h;
                     h.t = q.t; h.inst = q.inst; h.c.t = q.ct; h.c.a = q.ca; h.c.b = q.cb;
                     WorldHit wh;
                     world_hit<F, COUNT>(sc, ld3(r.o), rd, h, wh, wk);
                     const DInstance& in = sc.instances[h.inst];
-                    if (primary_trip) { distance = h.t; hit_id = in.node_id; }
+                    if (r.flags & 1u) { a.distance[r.slot] = h.t; a.hit_id[r.slot] = in.node_id; }
+                    uint64_t stream = 0;
+                    if constexpr (F & RTF_INLINE_LIGHTS) {          // only the area lights draw random numbers
+                        if (a.mode == 0) stream = rng_stream(rp.seed, r.slot, 0);
+                        else stream = rng_stream(rp.seed, a.list[r.slot / rp.aa_rays], 1 + r.slot % rp.aa_rays);
+                    }
                     Spawn spawn[RT_SHADE_MAX_SPAWN];
                     uint32_t nspawn;
                     d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, spawn, nspawn, wk);
-                    color = color + rw * local;
+                    acc_contribute(la, r.slot, rw * local, a.acc, a.acc_flags);
                     for (uint32_t i = 0; i < nspawn; ++i) {
                         const Spawn& sn = spawn[i];
                         if (sn.shadow) {
                             if (ns_new >= RT_MAX_SHADOW_JOBS) { RT_COUNT(wk, stack_overflows); continue; }
                             ShadowJob& s = shadows[ns_new++];
-                            st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w);
+                            st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w); s.slot = r.slot;
                         } else {
                             // the first new ray takes over its parent's slot, the others go on top
-                            int dst;
-                            if (!reused) { dst = slot; reused = true; }
-                            else {
-                                if (top >= RT_MAX_STACK) { RT_COUNT(wk, stack_overflows); continue; }
-                                dst = top++;
-                            }
-                            LaneRay& s = stack[dst];
-                            st3(s.o, sn.o); st3(s.d, sn.d); st3(s.w, rw * sn.w); st3(s.c, sn.c);
-                            s.depth = r.depth - 1; s.path = child_path(r.path, sn.ordinal);
+                            LaneRay nr;
+                            st3(nr.o, sn.o); st3(nr.d, sn.d); st3(nr.w, rw * sn.w); st3(nr.c, sn.c);
+                            nr.depth = r.depth - 1; nr.path = child_path(r.path, sn.ordinal); nr.slot = r.slot; nr.flags = 0u;
+                            if (!reused) { stack[slot] = nr; reused = true; }
+                            else if (top < RT_MAX_STACK) stack[top++] = nr;
+                            else if (a.last_round || !hand_on(nr)) RT_COUNT(wk, stack_overflows);
                         }
                     }
                 }
@@ -390,22 +380,31 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         }
         sp = top;
         ns = ns_new;
+        if (draining) {
+            // the rays this trip spawned start the next round
+            int keep = 0;
+            for (int i = 0; i < sp; ++i) {
+                if (!hand_on(stack[i])) { if (keep != i) stack[keep] = stack[i]; ++keep; }
+            }
+            sp = keep;
+        }
     }
+    acc_flush(la, a.acc, a.acc_flags);
     if (a.mode == 0) flush_counters<COUNT>(a.counters, wk, cam, 0);
     else flush_counters<COUNT>(a.counters, wk, 0, cam);
 }
 
-// ------------------------------------------------------------------ split samples: accumulators -> f64
-// dst is the colour buffer (pass 1) or the AA sample buffer; leaves every accumulator zero again.
+// ------------------------------------------------------------------ accumulators -> f64
+// One accumulator per sample slot; dst is the colour buffer (pass 1) or the AA sample buffer.
+// Leaves every accumulator zero again.
 __global__ void __launch_bounds__(256)
-k_acc_resolve(unsigned long long* __restrict__ acc, uint32_t* __restrict__ acc_flags, const uint32_t* __restrict__ acc_out,
-              const unsigned int* __restrict__ acc_alloc, uint32_t acc_cap, double* __restrict__ dst) {
-    uint32_t n = min(*acc_alloc, acc_cap);
+k_acc_resolve(unsigned long long* __restrict__ acc, uint32_t* __restrict__ acc_flags, const unsigned int* __restrict__ count,
+              uint32_t per_count, uint32_t fixed_n, double* __restrict__ dst) {
+    const uint32_t n = count ? *count * per_count : fixed_n;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
         unsigned long long* limbs = acc + (size_t)slot * RT_ACC_LIMBS;
         uint32_t f = acc_flags[slot];
-        size_t out = acc_out[slot];
-        for (uint32_t ch = 0; ch < 3; ++ch) dst[3 * out + ch] = acc_value(limbs, f, ch);
+        for (uint32_t ch = 0; ch < 3; ++ch) dst[3 * (size_t)slot + ch] = acc_value(limbs, f, ch);
         for (uint32_t i = 0; i < RT_ACC_LIMBS; ++i) limbs[i] = 0ull;
         acc_flags[slot] = 0u;
     }
