@@ -143,7 +143,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
         s->lds_limit = lds_max > 0 ? (uint32_t)lds_max : 65536u;
         d.lds_blob = nullptr; d.lds_blob_bytes = 0;
-        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + 512u * RT_LDS_STACK * 4u <= s->lds_limit) {
+        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + RT_LDS_FIXED_BYTES(512u) <= s->lds_limit) {
             rc = upload(fs.lds_blob, s->owned, &d.lds_blob);
             if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
             d.lds_blob_bytes = (uint32_t)fs.lds_blob.size();
@@ -172,7 +172,7 @@ template <uint32_t F>
 int launch_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
     uint32_t block = 64, lds = 0;
     if (F & RTF_LDS_BVH) { block = 512; grid = std::max(1u, grid / 8); }   // one 512-thread workgroup per CU, the BVH blob in its LDS
-    if (F & RTF_MESH) lds = block * RT_LDS_STACK * 4u + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // BVH walk stacks (+ blob)
+    if (F & RTF_MESH) lds = RT_LDS_FIXED_BYTES(block) + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // walk stacks, job lists (+ blob)
     if (lds > 48u * 1024u) {
         auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -212,6 +212,14 @@ uint32_t idle_divisor() {
     return d;
 }
 
+uint32_t batch_limit() {
+    static const uint32_t b = [] { const char* e = std::getenv("RT_BATCH_LIMIT"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min<long>(v, RT_BATCH) : 4u; }();
+    return b;
+}
+uint32_t refill_min() {
+    static const uint32_t b = [] { const char* e = std::getenv("RT_REFILL_MIN"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min<long>(v, 64) : 16u; }();
+    return b;
+}
 uint32_t trace_rounds(uint32_t recursion_depth) {
     static const long forced = [] { const char* e = std::getenv("RT_TRACE_ROUNDS"); return e ? std::atol(e) : 0L; }();
     if (forced > 0) return (uint32_t)std::min<long>(forced, RT_MAX_ROUNDS);
@@ -311,19 +319,25 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     if ((e = s->lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
-    // With b rays taken per trip up to b x (spawn - 1) entries stay behind per level, and the last trip's pushes sit on top.
-    uint32_t batch = (s->ds.features & RTF_MESH) ? RT_BATCH : 1;
-    for (;; --batch) {
+    // Queries per trip.  Depth-first order (one ray per trip) needs at most per_level x depth + spawn + 1
+    // stack entries; several rays per trip are taken only while what they may push still leaves that much room.
+    uint32_t batch = batch_limit();
+    while (batch > 1 && batch * s->ds.max_shadow_spawn > RT_MAX_SHADOW_JOBS) --batch;
+    if (batch * s->ds.max_shadow_spawn > RT_MAX_SHADOW_JOBS) return fail(RT_ERR_CAPACITY, "rt_render: too many deferred shadow tests per hit");
+    uint32_t wide_sp_limit = 0;
+    {
         uint64_t per_level = s->ds.max_ray_spawn > 0 ? s->ds.max_ray_spawn - 1 : 0;
-        uint64_t need = batch * (per_level * rc.recursion_depth + s->ds.max_shadow_spawn + s->ds.max_ray_spawn) + 1;
-        if (need <= RT_MAX_STACK && batch * s->ds.max_shadow_spawn <= RT_MAX_SHADOW_JOBS) break;
-        if (batch == 1) return fail(RT_ERR_CAPACITY, "rt_render: recursion_depth x rays-per-hit exceeds the device ray stack");
+        uint64_t need1 = per_level * rc.recursion_depth + s->ds.max_ray_spawn + 1;
+        if (need1 > RT_MAX_STACK) return fail(RT_ERR_CAPACITY, "rt_render: recursion_depth x rays-per-hit exceeds the device ray stack");
+        uint64_t wide = need1 + (uint64_t)batch * s->ds.max_ray_spawn;
+        wide_sp_limit = wide <= RT_MAX_STACK ? (uint32_t)(RT_MAX_STACK - wide) : 0u;
     }
     TraceArgs ta{};
     ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
     ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
     ta.list = nullptr; ta.count = aa_count; ta.counters = counters; ta.mode = 0;
-    ta.batch = batch; ta.lane_mem = (uint8_t*)s->lane_mem.p;
+    ta.refill_min = refill_min();
+    ta.batch = batch; ta.wide_sp_limit = wide_sp_limit; ta.lane_mem = (uint8_t*)s->lane_mem.p;
     ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)s->acc.p; ta.acc_flags = (uint32_t*)s->acc_flags.p;
     // Rounds: a launch ends once its work has all been dealt out, and what the lanes still hold is
     // dealt out again by the next one.  A ray handed on is traced in the next round, so a chain of
@@ -479,6 +493,16 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
             fill_counters(aux->counters, c);
+        }
+        if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
+            DCounters c{};
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            const char* names[8] = {"trips", "phase A jobs", "walk descend", "walk refill", "walk leaf", "phase B rays", "", ""};
+            for (int i = 0; i < 6; ++i)
+                std::fprintf(stderr, "[rt] %-14s wave trips %12llu  lanes/trip %5.1f\n", names[i], c.prof[2 * i], c.prof[2 * i] ? (double)c.prof[2 * i + 1] / (double)c.prof[2 * i] : 0.0);
+            double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]);
+            std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
+                         100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
         }
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];

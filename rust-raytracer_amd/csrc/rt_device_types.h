@@ -15,9 +15,9 @@
 #include <stdint.h>
 
 #define RT_MAX_STACK 128       // secondary-ray stack entries per camera sample
-#define RT_BATCH 4             // rays a lane takes off its stack per trip when the scene has meshes
+#define RT_BATCH 8             // most scene queries (shadow tests + rays off the stack) a lane runs per trip
 #define RT_BVH_STACK 48        // BVH traversal stack entries (deeper trees are rejected at scene creation)
-#define RT_LDS_STACK 24        // ... of which this many live in LDS, the rest in the lane's global memory
+#define RT_LDS_STACK 16        // ... of which this many live in LDS, the rest in the lane's global memory
 #define RT_MAX_SHADOW_JOBS 32  // deferred shadow tests a lane may hold between two trips
 #define RT_CSG_MAX_HITS 16     // hits per composite-shape list
 #define RT_CSG_ARENA 96        // hits across all live lists of one composite query
@@ -227,4 +227,9 @@ struct DRenderParams {
 struct DCounters {             // mirrors RtCounters' first ten fields
     unsigned long long rays_primary, rays_secondary, rays_shadow, rays_aa, aa_pixels,
         instance_tests, box_tests, tri_tests, shade_evals, stack_overflows;
+    // lane occupancy of the trace kernel's phases (instrumented launches only): per phase the
+    // number of loop trips a wave made and the number of lanes that had work in them
+    unsigned long long prof[16];
 };
+enum { PF_TRIPS = 0, PF_TRIP_LANES, PF_A_ITERS, PF_A_LANES, PF_T_ITERS, PF_T_LANES, PF_T_REFILLS, PF_T_REFILL_LANES,
+       PF_T_LEAF_ITERS, PF_T_LEAF_LANES, PF_B_ITERS, PF_B_LANES, PF_CYC_A, PF_CYC_T, PF_CYC_B, PF_CYC_FETCH };

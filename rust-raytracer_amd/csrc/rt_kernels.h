@@ -113,6 +113,7 @@ RT_DEV void flush_counters(DCounters* g, const Work<COUNT>& wk, unsigned long lo
     atomicAdd(&g->tri_tests, wk.tri_tests);
     atomicAdd(&g->shade_evals, wk.shade_evals);
     atomicAdd(&g->stack_overflows, wk.stack_overflows);
+    for (int i = 0; i < 16; ++i) if (wk.prof[i]) atomicAdd(&g->prof[i], wk.prof[i]);
 }
 
 struct TraceArgs {
@@ -133,7 +134,9 @@ struct TraceArgs {
     uint32_t last_round;      // 1: run every ray to completion, hand nothing on
     unsigned int* idle_count; // lanes of this launch that have run out of work
     uint32_t idle_limit;      // ... and how many of them end the round
-    uint32_t batch;           // rays a lane takes off its stack per trip (<= RT_BATCH; 1 without meshes)
+    uint32_t batch;           // scene queries per lane per trip (<= RT_BATCH)
+    uint32_t refill_min;      // free lanes it takes to interrupt the BVH walk for new queries
+    uint32_t wide_sp_limit;   // deepest stack from which a lane may still take several rays in one trip
     uint8_t* lane_mem;        // RT_LANE_BYTES per launched thread
     const LaneRay* in_items;
     const unsigned int* in_count;
@@ -156,8 +159,8 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         for (uint32_t i = threadIdx.x; i < sc.lds_blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    constexpr bool BATCHED = (F & RTF_MESH) != 0;    // scenes with meshes: several rays per trip, walked together
-    constexpr int KB = BATCHED ? RT_BATCH : 1;
+    constexpr bool BATCHED = (F & RTF_MESH) != 0;    // scenes with meshes: the trip's queries walk the BVH together
+    constexpr int KB = RT_BATCH;
     const uint32_t W = rp.cam.width;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (W + 7) / 8;
@@ -177,7 +180,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
     int sp = 0;                         // pending camera / secondary rays
-    uint32_t ns = 0;                    // pending shadow tests (spawned by the previous trip)
+    uint32_t ns = 0, sh_head = 0;       // pending shadow tests: a ring of RT_MAX_SHADOW_JOBS entries starting at sh_head
     bool exhausted = false;             // this lane asked for work and there was none left
     bool draining = false;              // enough lanes are idle: finish this trip, hand the rest on
     bool idle_counted = false;
@@ -194,6 +197,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         return true;
     };
 
+    long long t_prof = COUNT ? clock64() : 0;
     for (;;) {
         // ---------------- take work until a.batch rays are pending
         auto take = [&](bool need) {                                // one item for every lane that asks
@@ -252,7 +256,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         };
         if (!draining) {
             for (int f = 0; f < KB; ++f)
-                if (!take((uint32_t)sp < a.batch && !exhausted)) break;
+                if (!take((uint32_t)sp + ns < a.batch && !exhausted)) break;
             // Once enough lanes of the launch have run out of work, the others stop after the trip
             // they are in and hand their rays on, so that the next round can deal them out evenly.
             if (!a.last_round) {
@@ -269,10 +273,16 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
         }
         if (__ballot(sp > 0 || ns > 0 || !(exhausted || draining)) == 0ull) break;
         if (sp == 0 && ns == 0) continue;
+        RT_PROF(wk, PF_TRIPS, PF_TRIP_LANES);
+        RT_PROF_CYC(wk, PF_CYC_FETCH, t_prof);
 
-        // ---------------- one trip: the shadow tests spawned by the previous trip plus up to
-        // a.batch rays off the stack (they stay in their stack slots until phase B)
-        const uint32_t npop = min(a.batch, (uint32_t)sp);
+        // ---------------- one trip: a.batch queries — pending shadow tests first, then rays off the
+        // stack (they stay in their stack slots until phase B).  The same number for every lane
+        // that has them, so that the lanes of a wave finish the phases together.
+        const uint32_t nsh = min(ns, a.batch);
+        // (a stack too full for a whole batch of hits to push onto falls back to one ray per trip,
+        // plain depth-first order, whose need the host has checked against the stack's size)
+        const uint32_t npop = min((uint32_t)sp <= a.wide_sp_limit ? a.batch - nsh : min(a.batch - nsh, 1u), (uint32_t)sp);
         if (draining) {
             // everything below the rays of this trip goes to the next round now
             int keep = 0;
@@ -283,20 +293,23 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
             sp = keep + (int)npop;
         }
         const int sp0 = sp;
-        const uint32_t njobs = ns + npop;
+        const uint32_t njobs = nsh + npop;
         // phase A: gate, every primitive except the un-wrapped meshes
+        uint32_t live_mask = 0;                                     // queries that still need the meshes
         for (uint32_t j = 0; j < njobs; ++j) {
+            RT_PROF(wk, PF_A_ITERS, PF_A_LANES);
             TraceJob& q = jobs[j];
-            const bool shadow = j < ns;
+            const bool shadow = j < nsh;
             d3 o, d;
             double max_distance = 0.0;
             if (shadow) {
-                const ShadowJob& s = shadows[j];
+                const uint32_t si = (sh_head + j) % RT_MAX_SHADOW_JOBS;
+                const ShadowJob& s = shadows[si];
                 o = ld3(s.o); d = ld3(s.d); max_distance = s.dist;
-                q.src = RT_LANE_OFF_SHADOW + j * (uint32_t)sizeof(ShadowJob);
+                q.src = RT_LANE_OFF_SHADOW + si * (uint32_t)sizeof(ShadowJob);
                 RT_COUNT(wk, rays_shadow);
             } else {
-                const uint32_t slot = (uint32_t)sp0 - 1u - (j - ns);
+                const uint32_t slot = (uint32_t)sp0 - 1u - (j - nsh);
                 const LaneRay& r = stack[slot];
                 o = ld3(r.o); d = ld3(r.d);
                 const d3 rc = ld3(r.c);
@@ -317,21 +330,30 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
             q.inst = h.inst; q.found = found ? 1u : 0u;
             q.ct = h.c.t; q.ca = h.c.a; q.cb = h.c.b;
             q.flags = (shadow ? 1u : 0u) | ((shadow && found) ? 2u : 0u);   // an occluded shadow test is settled
+            if (!(shadow && found)) live_mask |= 1u << j;
         }
+        RT_PROF_CYC(wk, PF_CYC_A, t_prof);
         // phase T: the meshes, for all of the trip's queries
-        if constexpr (BATCHED) mesh_walk_batch<(F & RTF_LDS_BVH) != 0, COUNT>(sc, lane_mem, jobs, njobs, wk);
+        if constexpr (BATCHED) {
+            // (lanes without work this trip have skipped it; the others run the walk together)
+            mesh_walk_batch<(F & RTF_LDS_BVH) != 0, COUNT>(sc, lane_mem, live_mask, a.refill_min, wk);
+        }
+        RT_PROF_CYC(wk, PF_CYC_T, t_prof);
         // phase B: add the visible lights, shade the hits, push what they spawn
-        for (uint32_t j = 0; j < ns; ++j) {
+        for (uint32_t j = 0; j < nsh; ++j) {
             if (!jobs[j].found) {
-                acc_contribute(la, shadows[j].slot, ld3(shadows[j].w), a.acc, a.acc_flags);
+                const ShadowJob& s = shadows[(sh_head + j) % RT_MAX_SHADOW_JOBS];
+                acc_contribute(la, s.slot, ld3(s.w), a.acc, a.acc_flags);
                 RT_COUNT(wk, shade_evals);
             }
         }
-        uint32_t ns_new = 0;
+        sh_head = (sh_head + nsh) % RT_MAX_SHADOW_JOBS;
+        ns -= nsh;
         int top = sp0;
         for (uint32_t k = 0; k < npop; ++k) {
+            RT_PROF(wk, PF_B_ITERS, PF_B_LANES);
             const int slot = sp0 - 1 - (int)k;
-            const TraceJob q = jobs[ns + k];
+            const TraceJob q = jobs[nsh + k];
             bool reused = false;                                    // the slot holds a new ray
             if (!(q.flags & 4u)) {
                 const LaneRay r = stack[slot];
@@ -358,8 +380,9 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                     for (uint32_t i = 0; i < nspawn; ++i) {
                         const Spawn& sn = spawn[i];
                         if (sn.shadow) {
-                            if (ns_new >= RT_MAX_SHADOW_JOBS) { RT_COUNT(wk, stack_overflows); continue; }
-                            ShadowJob& s = shadows[ns_new++];
+                            if (ns >= RT_MAX_SHADOW_JOBS) { RT_COUNT(wk, stack_overflows); continue; }
+                            ShadowJob& s = shadows[(sh_head + ns) % RT_MAX_SHADOW_JOBS];
+                            ++ns;
                             st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w); s.slot = r.slot;
                         } else {
                             // the first new ray takes over its parent's slot, the others go on top
@@ -379,7 +402,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
             }
         }
         sp = top;
-        ns = ns_new;
+        RT_PROF_CYC(wk, PF_CYC_B, t_prof);
         if (draining) {
             // the rays this trip spawned start the next round
             int keep = 0;

@@ -16,10 +16,13 @@
 #define RT_MIN_CONTRIBUTION 0.003    // Ray::MIN_CONTRIBUTION, src/geometry/ray.rs:13
 #define RT_PI 3.14159265358979323846
 
-// Dynamic LDS of the trace kernel: [BVH walk stacks: RT_LDS_STACK rows of blockDim.x words][BVH blob].
+// Dynamic LDS of the trace kernel:
+//   [BVH walk stacks: RT_LDS_STACK rows of blockDim.x words][per wave: list of 64 x RT_BATCH walk jobs][BVH blob]
 extern __shared__ __align__(16) uint8_t rt_lds_dynamic[];
+#define RT_LDS_FIXED_BYTES(threads) ((threads) * (RT_LDS_STACK + RT_BATCH) * 4u)
 RT_DEV uint32_t* rt_lds_stack() { return reinterpret_cast<uint32_t*>(rt_lds_dynamic); }
-RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic + (size_t)blockDim.x * RT_LDS_STACK * 4u; }
+RT_DEV uint32_t* rt_lds_joblist() { return reinterpret_cast<uint32_t*>(rt_lds_dynamic) + (size_t)blockDim.x * RT_LDS_STACK + (threadIdx.x >> 6) * 64u * RT_BATCH; }
+RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic + (size_t)RT_LDS_FIXED_BYTES(blockDim.x); }
 
 #define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
@@ -41,7 +44,13 @@ struct Details {         // Intersect fields in the primitive's own space (geome
 template <bool COUNT>
 struct Work {            // per-thread work counters, compiled out when COUNT is false
     unsigned long long instance_tests, box_tests, tri_tests, shade_evals, rays_shadow, rays_secondary, stack_overflows;
+    unsigned long long prof[16];
 };
+// Occupancy probe: one lane of the wave counts the trip, every lane with work counts itself.
+#define RT_PROF(w, iters, lanes) do { if (COUNT) { unsigned long long m_ = __ballot(1); \
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) { (w).prof[iters]++; (w).prof[lanes] += (unsigned long long)__popcll(m_); } } } while (0)
+#define RT_PROF_CYC(w, which, t0) do { if (COUNT) { unsigned long long m_ = __ballot(1); long long t1_ = clock64(); \
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) (w).prof[which] += (unsigned long long)(t1_ - (t0)); (t0) = t1_; } } while (0)
 
 #define RT_COUNT(w, field) do { if (COUNT) (w).field++; } while (0)
 
@@ -374,23 +383,46 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
     return found;
 }
 
-// The mesh part of all of a lane's queries of one trip in ONE loop.  A job is (query j of the
-// lane's table, mesh instance m); a lane whose job ends takes its next job without leaving
-// the loop, so the lanes of a wave run out of work together instead of each idling until the
-// slowest single walk is over.  Setting up a job (ray -> instance space, root box) is only
-// done when RT_REFILL_MIN lanes are waiting for it or nobody is walking any more.
-// The walk itself is mesh_walk's.  Results are merged into jobs[j]: the closest hit over the
-// instances already tested (ties go to the earlier instance, src/scene.rs:200-217), or the
-// any-hit verdict.  The walk stack lives in LDS (one column per thread), its overflow in the
-// lane's global memory.
-#define RT_REFILL_MIN 16
+// The mesh part of all queries of a WAVE's trip in one loop.  Each lane brings up to RT_BATCH
+// queries (jobs[], bit j of live_mask set for those that still need the meshes); how long a query
+// walks differs by two orders of magnitude and the queries of one lane are alike (they belong to
+// the same few pixels), so the wave pools them: the live queries of all 64 lanes go into a list
+// in LDS and every lane takes the next one off the list whenever it is free.  A query is walked
+// through every mesh instance by the lane that took it; the result is merged into the owner's
+// jobs[] entry: the closest hit over the instances already tested (ties go to the earlier
+// instance, src/scene.rs:200-217), or the any-hit verdict.
+// Setting up (taking a query, ray -> instance space, root box) is only done when refill_min
+// lanes are waiting for it or nobody is walking any more.  The walk itself is mesh_walk's; its
+// stack lives in LDS (one column per thread), the overflow in the lane's global memory.
 template <bool LDS, bool COUNT>
-RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs, uint32_t njobs, Work<COUNT>& wk) {
+RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_mask, uint32_t refill_min, Work<COUNT>& wk) {
     const uint32_t nm = sc.num_mesh_instances;
-    uint32_t j = 0, m = 0;
-    while (j < njobs && (jobs[j].flags & 2u)) ++j;
-    bool more = j < njobs && nm > 0;
-    bool walking = false;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // the wave's job list: (owner lane << 8) | query index
+    uint32_t* list = rt_lds_joblist();
+    uint32_t total = 0;
+    if (nm > 0) {
+        for (uint32_t j = 0; j < RT_BATCH; ++j) {
+            const bool live = (live_mask >> j) & 1u;
+            const unsigned long long m = __ballot(live);
+            if (live) list[total + (uint32_t)__popcll(m & lt)] = (lane << 8) | j;
+            total += (uint32_t)__popcll(m);
+        }
+    }
+    if (total == 0) return;
+    // queries written by phase A and the rays behind them are read by other lanes of the wave from here on
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint8_t* wave_mem = lane_mem - (size_t)lane * RT_LANE_BYTES;      // lane 0's block; the wave's blocks are consecutive
+    uint32_t next = 0;                                               // wave-uniform: first query not yet taken
+    bool have = false, walking = false;
+    TraceJob* q = nullptr;
+    const double* od = nullptr;
+    uint32_t m = 0;
+    // the query being walked: running result over the mesh instances
+    double qt = 0.0, qct = 0.0;
+    uint32_t qinst = 0, qfound = 0, qca = 0;
     LRay lr; lr.o = mk3(0.0, 0.0, 0.0); lr.d = lr.o;
     d3 inv = lr.o;
     double best = 0.0, tmax = 0.0, inv_s = 1.0;
@@ -414,16 +446,32 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
         --sp;
         return sp < RT_LDS_STACK ? lstack[sp * lstride] : gstack[sp - RT_LDS_STACK];
     };
+    auto finish_query = [&]() {                                       // write the merged result back to its owner
+        q->t = qt; q->inst = qinst; q->found = qfound; q->ct = qct; q->ca = qca; q->cb = 0u;
+        have = false;
+    };
     for (;;) {
-        const bool need = !walking && more;
+        const bool need = !walking && (have || next < total);
         const unsigned long long nmask = __ballot(need), wmask = __ballot(walking);
         if (nmask == 0ull && wmask == 0ull) break;
-        if (nmask != 0ull && (wmask == 0ull || __popcll(nmask) >= RT_REFILL_MIN)) {
-            if (need) {
-                do {   // next job whose ray reaches the mesh's bounding box
-                    const TraceJob& q = jobs[j];
-                    const double* od = reinterpret_cast<const double*>(lane_mem + q.src);
-                    any = (q.flags & 1u) != 0;
+        if (nmask != 0ull && (wmask == 0ull || __popcll(nmask) >= refill_min)) {
+            // free lanes take the next queries off the list
+            const bool want = need && !have;
+            const unsigned long long jm = __ballot(want);
+            const uint32_t idx = next + (uint32_t)__popcll(jm & lt);
+            next += (uint32_t)__popcll(jm);
+            if (want && idx < total) {
+                const uint32_t e = list[idx];
+                uint8_t* owner = wave_mem + (size_t)(e >> 8) * RT_LANE_BYTES;
+                q = reinterpret_cast<TraceJob*>(owner + RT_LANE_OFF_JOBS) + (e & 255u);
+                od = reinterpret_cast<const double*>(owner + q->src);
+                any = (q->flags & 1u) != 0;
+                qt = q->t; qinst = q->inst; qfound = q->found; qct = q->ct; qca = q->ca;
+                have = true; m = 0;
+            }
+            if (need && have) {
+                RT_PROF(wk, PF_T_REFILLS, PF_T_REFILL_LANES);
+                do {   // next mesh instance whose bounding box the ray reaches
                     inst = sc.mesh_instances[m];
                     const DInstance& in = sc.instances[inst];
                     const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
@@ -431,7 +479,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
                     lr = to_local(in.x, ld3(od), ld3(od + 3), s, inv_s);
                     RT_COUNT(wk, instance_tests);
                     inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
-                    tmax = q.t * s;
+                    tmax = qt * s;
                     inclusive = in.is_root != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
@@ -440,11 +488,10 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
                         gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
                         lnodes = reinterpret_cast<const LBvhNode*>(rt_lds_base() + mesh.lds_node_off);
                         ltris = reinterpret_cast<const LMeshTri*>(rt_lds_base() + mesh.lds_tri_off);
-                    } else {
-                        if (++m == nm) { m = 0; ++j; while (j < njobs && (jobs[j].flags & 2u)) ++j; }
-                        more = j < njobs;
+                    } else if (++m == nm) {
+                        finish_query();
                     }
-                } while (!walking && more);
+                } while (!walking && have);
             }
         }
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
@@ -452,6 +499,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
             bool h0, h1;
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
+            RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
                 const LBvhNode& n = lnodes[cur];
                 h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
@@ -473,6 +521,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
         }
         if (walking) {
             if (cur != RT_WALK_DONE) {                                // the leaf's triangles
+                RT_PROF(wk, PF_T_LEAF_ITERS, PF_T_LEAF_LANES);
                 uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
@@ -488,26 +537,27 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, TraceJob* jobs,
                 }
                 cur = (any && found) ? RT_WALK_DONE : pop();
             }
-            if (cur == RT_WALK_DONE) {                                // job over: merge, move on
-                TraceJob& q = jobs[j];
-                bool next_query = false;
+            if (cur == RT_WALK_DONE) {                                // this instance is done: merge, move on
+                bool settled = false;
                 if (found) {
-                    if (any) { q.found = 1u; next_query = true; }
+                    if (any) { qfound = 1u; settled = true; }
                     else {
                         double tw = best * inv_s;
-                        if (tw < q.t || (tw == q.t && q.found && inst < q.inst)) {
-                            q.t = tw; q.inst = inst; q.found = 1u;
-                            q.ct = best; q.ca = tri; q.cb = 0u;
+                        if (tw < qt || (tw == qt && qfound && inst < qinst)) {
+                            qt = tw; qinst = inst; qfound = 1u;
+                            qct = best; qca = tri;
                         }
                     }
                 }
                 ++m;
-                if (next_query || m == nm) { m = 0; ++j; while (j < njobs && (jobs[j].flags & 2u)) ++j; }
-                more = j < njobs;
+                if (settled || m == nm) finish_query();
                 walking = false;
             }
         }
     }
+    // results were written by other lanes of the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // ------------------------------------------------------------------ basic (non-composite) primitives
