@@ -16,6 +16,7 @@
 #include "rt_amd.h"
 #include "rt_flatten.hpp"
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 namespace {
 
@@ -66,7 +67,9 @@ struct RtScene {
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
-    DeviceBuf queue[2], acc, acc_flags, lane_mem;   // hand-over queues between rounds, split-sample accumulators
+    DeviceBuf queue[2], acc, acc_flags, lane_mem;
+    // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;   // hand-over queues between rounds, split-sample accumulators
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -94,7 +97,9 @@ void rt_scene_destroy(RtScene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
     for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
-                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->lane_mem}) b->release();
+                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->lane_mem,
+                         &s->wf_rays[0], &s->wf_rays[1], &s->wf_shadows[0], &s->wf_shadows[1], &s->wf_rjobs, &s->wf_sjobs, &s->wf_contrib,
+                         &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -199,8 +204,64 @@ int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t strea
     return launch_variant<RTF_ALL>(count, grid, stream, ds, rp, ta);
 }
 
-// Layout of the per-frame scalar block (u32 words), zeroed at the start of every frame.
 constexpr uint32_t RT_MAX_ROUNDS = 40;
+// ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
+template <uint32_t F>
+int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
+    if (which == 0) {
+        if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+        else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+    } else {
+        if (count) hipLaunchKernelGGL((k_wf_shade<F, true>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+        else hipLaunchKernelGGL((k_wf_shade<F, false>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+constexpr uint32_t V_NO_INLINE = RTF_ALL & ~RTF_INLINE_LIGHTS;
+int wf_launch(int which, uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
+    auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
+    if (covers(0u)) return wf_launch_variant<0u>(which, count, grid, stream, ds, rp, wa);
+    if (covers(V_MESH)) return wf_launch_variant<V_MESH>(which, count, grid, stream, ds, rp, wa);
+    if (covers(V_BALLS)) return wf_launch_variant<V_BALLS>(which, count, grid, stream, ds, rp, wa);
+    if (covers(V_CSG)) return wf_launch_variant<V_CSG>(which, count, grid, stream, ds, rp, wa);
+    return wf_launch_variant<V_NO_INLINE>(which, count, grid, stream, ds, rp, wa);
+}
+int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {
+    const bool lds_bvh = ds.lds_blob_bytes != 0;
+    const uint32_t block = lds_bvh ? 1024u : 256u, grid = lds_bvh ? num_cus : num_cus * 8u;
+    const uint32_t lds = block * RT_WF_LDS_STACK * 4u + 2048u + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
+    const void* fn = lds_bvh ? (count ? (const void*)k_wf_walk<true, true> : (const void*)k_wf_walk<true, false>)
+                             : (count ? (const void*)k_wf_walk<false, true> : (const void*)k_wf_walk<false, false>);
+    if (lds > 48u * 1024u) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea));
+    }
+    if (lds_bvh) {
+        if (count) hipLaunchKernelGGL((k_wf_walk<true, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
+        else hipLaunchKernelGGL((k_wf_walk<true, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
+    } else {
+        if (count) hipLaunchKernelGGL((k_wf_walk<false, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
+        else hipLaunchKernelGGL((k_wf_walk<false, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("k_wf_walk launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+// u32 words of the pipeline's scalar block, per pass: queue fill [generation][rays, shadow tests], walk list fill and cursor per generation
+constexpr uint32_t WF_MAX_GEN = RT_MAX_ROUNDS + 2;
+constexpr uint32_t WF_N = 0, WF_WALK_COUNT = WF_N + 2 * RT_WF_Q * (WF_MAX_GEN + 1), WF_WALK_NEXT = WF_WALK_COUNT + RT_WF_Q * (WF_MAX_GEN + 1),
+                   WF_PASS_WORDS = WF_WALK_NEXT + RT_WF_Q * (WF_MAX_GEN + 1);
+constexpr uint32_t WF_DROPPED = 2 * WF_PASS_WORDS;
+constexpr size_t WF_SCALAR_BYTES = (WF_DROPPED + 4) * 4;
+bool use_wavefront(uint32_t features) {
+    static const int forced = [] { const char* e = std::getenv("RT_PATH"); return !e ? 0 : (std::strcmp(e, "persistent") == 0 ? 1 : (std::strcmp(e, "queues") == 0 ? 2 : 0)); }();
+    if (features & RTF_INLINE_LIGHTS) return false;      // visibility inside the shader: persistent kernel only
+    return forced != 1;
+}
+
+// Layout of the per-frame scalar block (u32 words), zeroed at the start of every frame.
 constexpr uint32_t SC_AA_COUNT = 0, SC_ACC_ALLOC0 = 1, SC_ACC_ALLOC1 = 2;
 constexpr uint32_t SC_NEXT0 = 16, SC_NEXT1 = SC_NEXT0 + RT_MAX_ROUNDS + 1;          // work counters, one per round
 constexpr uint32_t SC_QUEUE0 = SC_NEXT1 + RT_MAX_ROUNDS + 1, SC_QUEUE1 = SC_QUEUE0 + RT_MAX_ROUNDS + 1;   // queue fill, one per round
@@ -366,8 +427,63 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         HIP_TRY(hipGetLastError());
         return RT_OK;
     };
+    // ---- the other schedule: ray queues in HBM, one generation of rays per set of launches
+    const bool wavefront = use_wavefront(s->ds.features);
+    const uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
+    WfArgs wa{};
+    if (wavefront) {
+        for (auto& b : s->wf_rays) if ((e = b.ensure((size_t)wf_cap * sizeof(LaneRay))) != RT_OK) return e;
+        for (auto& b : s->wf_shadows) if ((e = b.ensure((size_t)wf_cap * sizeof(ShadowJob))) != RT_OK) return e;
+        if ((e = s->wf_rjobs.ensure((size_t)wf_cap * sizeof(TraceJob))) != RT_OK) return e;
+        if ((e = s->wf_sjobs.ensure((size_t)wf_cap * sizeof(TraceJob))) != RT_OK) return e;
+        if ((e = s->wf_contrib.ensure((size_t)wf_cap * 2 * sizeof(WfContribution))) != RT_OK) return e;
+        if ((e = s->wf_walk_list.ensure((size_t)wf_cap * 2 * sizeof(uint32_t))) != RT_OK) return e;
+        if ((e = s->wf_overflow.ensure((size_t)s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;
+        if ((e = s->wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
+        HIP_TRY(hipMemsetAsync(s->wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
+        wa.rjobs = (TraceJob*)s->wf_rjobs.p; wa.sjobs = (TraceJob*)s->wf_sjobs.p;
+        wa.sub_rays = wf_cap / RT_WF_Q; wa.sub_shadows = wf_cap / RT_WF_Q; wa.cap_rays = wa.sub_rays * RT_WF_Q;
+        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min();
+        wa.contrib = (WfContribution*)s->wf_contrib.p;
+        wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
+        wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
+        wa.dropped = (unsigned int*)s->wf_scalars.p + WF_DROPPED;
+        wa.rows = (const uint32_t*)s->rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
+    }
+    auto run_wavefront = [&](uint32_t mode, double* dst) -> int {
+        unsigned int* ws = (unsigned int*)s->wf_scalars.p + mode * WF_PASS_WORDS;
+        const uint32_t generations = std::min(rc.recursion_depth + 1, WF_MAX_GEN);
+        const uint32_t grid = std::max(1u, (uint32_t)s->num_cus * 16 / RT_WF_Q) * RT_WF_Q;   // a whole number of workgroups per sub-queue
+        wa.mode = mode;
+        wa.list = (const uint32_t*)s->list.p;
+        // generation 0 into queue set 0
+        wa.out_rays = (LaneRay*)s->wf_rays[0].p; wa.out_shadows = (ShadowJob*)s->wf_shadows[0].p; wa.n_out = ws + WF_N;
+        hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
+        HIP_TRY(hipGetLastError());
+        for (uint32_t g = 0; g < generations; ++g) {
+            wa.rays = (LaneRay*)s->wf_rays[g & 1].p; wa.shadows = (ShadowJob*)s->wf_shadows[g & 1].p; wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
+            wa.out_rays = (LaneRay*)s->wf_rays[(g + 1) & 1].p; wa.out_shadows = (ShadowJob*)s->wf_shadows[(g + 1) & 1].p; wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
+            wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g; wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g;
+            int lrc = wf_launch(0, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
+            if (lrc != RT_OK) return lrc;
+            if (s->ds.features & RTF_MESH) {
+                lrc = wf_launch_walk(count_work, (uint32_t)s->num_cus, stream, s->ds, wa);
+                if (lrc != RT_OK) return lrc;
+            }
+            lrc = wf_launch(1, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
+            if (lrc != RT_OK) return lrc;
+            hipLaunchKernelGGL(k_wf_accumulate, dim3(grid), dim3(256), 0, stream, wa);
+            HIP_TRY(hipGetLastError());
+        }
+        if (mode == 0)
+            hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, wa.acc, wa.acc_flags, (const unsigned int*)nullptr, 0u, (uint32_t)npix, dst);
+        else
+            hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, wa.acc, wa.acc_flags, (const unsigned int*)aa_count, rc.aa_rays, 0u, dst);
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    };
     if (num_rows > 0) {
-        int lrc = run_rounds(0, std::min(tiles, max_waves), (double*)s->color.p);
+        int lrc = wavefront ? run_wavefront(0, (double*)s->color.p) : run_rounds(0, std::min(tiles, max_waves), (double*)s->color.p);
         if (lrc != RT_OK) return lrc;
     }
     HIP_TRY(hipEventRecord(s->ev[1], stream));
@@ -381,7 +497,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
                            (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
         HIP_TRY(hipGetLastError());
         ta.list = (const uint32_t*)s->list.p;
-        int lrc = run_rounds(1, max_waves, (double*)s->samples.p);
+        int lrc = wavefront ? run_wavefront(1, (double*)s->samples.p) : run_rounds(1, max_waves, (double*)s->samples.p);
         if (lrc != RT_OK) return lrc;
         hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
                            (const double*)s->samples.p, (double*)s->color.p, (double*)s->distance.p);
@@ -440,6 +556,11 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
             HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
+            if (s->wf_scalars.p && use_wavefront(s->ds.features)) {
+                unsigned int dropped = 0;
+                HIP_TRY(hipMemcpy(&dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof dropped, hipMemcpyDeviceToHost));
+                c.stack_overflows += dropped;
+            }
             fill_counters(d_aux->counters, c);
         }
     }
@@ -492,6 +613,11 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
+            if (s->wf_scalars.p && use_wavefront(s->ds.features)) {
+                unsigned int dropped = 0;
+                HIP_TRY(hipMemcpy(&dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof dropped, hipMemcpyDeviceToHost));
+                c.stack_overflows += dropped;
+            }
             fill_counters(aux->counters, c);
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
@@ -503,6 +629,24 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]);
             std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
                          100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
+        }
+        if (std::getenv("RT_DEBUG_ROUNDS") && s->wf_scalars.p && use_wavefront(s->ds.features)) {   // queue fill per generation
+            std::vector<unsigned int> ws(WF_SCALAR_BYTES / 4);
+            HIP_TRY(hipMemcpy(ws.data(), s->wf_scalars.p, WF_SCALAR_BYTES, hipMemcpyDeviceToHost));
+            for (int pass = 0; pass < 2; ++pass) {
+                std::fprintf(stderr, "[rt] pass %d rays+shadow tests per generation (largest sub-queue):", pass);
+                for (uint32_t g = 0; g <= RT_MAX_ROUNDS; ++g) {
+                    unsigned long long nr = 0, ns = 0; unsigned int mx = 0;
+                    for (uint32_t q = 0; q < RT_WF_Q; ++q) {
+                        unsigned int a0 = ws[pass * WF_PASS_WORDS + WF_N + 2 * RT_WF_Q * g + 2 * q], a1 = ws[pass * WF_PASS_WORDS + WF_N + 2 * RT_WF_Q * g + 2 * q + 1];
+                        nr += a0; ns += a1; mx = std::max(mx, std::max(a0, a1));
+                    }
+                    if (nr + ns == 0) break;
+                    std::fprintf(stderr, " %llu+%llu(%u)", nr, ns, mx);
+                }
+                std::fprintf(stderr, "\n");
+            }
+            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_rays[0].bytes / sizeof(LaneRay) / RT_WF_Q), ws[WF_DROPPED]);
         }
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];
