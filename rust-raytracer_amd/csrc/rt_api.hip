@@ -130,7 +130,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     UP(instances, fs.instances); UP(mesh_instances, fs.mesh_instances); UP(prims, fs.prims); UP(tris, fs.tris); UP(polys, fs.polys); UP(points, fs.points);
     UP(faced, fs.faced); UP(meshes, fs.meshes); UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris);
     UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(csg_roots, fs.csg_roots); UP(csg_ops, fs.csg_ops);
-    UP(csg_leaves, fs.csg_leaves); UP(shaders, fs.shaders); UP(shader_child_idx, fs.shader_child_idx);
+    UP(csg_leaves, fs.csg_leaves); UP(shaders, fs.shaders); UP(shader_bounds, fs.shader_bounds); UP(shader_child_idx, fs.shader_child_idx);
     UP(shader_child_weight, fs.shader_child_weight); UP(chain_nmaps, fs.chain_nmaps); UP(normal_maps, fs.normal_maps);
     UP(images, fs.images); UP(texels, fs.texels); UP(gamma_lut, fs.gamma_lut); UP(lights, fs.lights);
 #undef UP

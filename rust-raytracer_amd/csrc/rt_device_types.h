@@ -191,6 +191,7 @@ struct DScene {
     const DCsgOp* csg_ops;
     const DCsgLeaf* csg_leaves;
     const DShader* shaders;
+    const uint32_t* shader_bounds;   // per shader: most rays (low 16 bits) and most deferred shadow tests (high bits) a hit on it can ask for
     const uint32_t* shader_child_idx;
     const double* shader_child_weight;
     const uint32_t* chain_nmaps;

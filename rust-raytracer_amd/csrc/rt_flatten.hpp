@@ -124,6 +124,7 @@ struct FlatScene {
     std::vector<DCsgOp> csg_ops;
     std::vector<DCsgLeaf> csg_leaves;
     std::vector<DShader> shaders;
+    std::vector<uint32_t> shader_bounds;
     std::vector<uint32_t> shader_child_idx;
     std::vector<double> shader_child_weight;
     std::vector<uint32_t> chain_nmaps;
@@ -438,6 +439,12 @@ private:
         for (uint32_t i = 0; i < fs_.instances.size(); ++i) {
             const DPrim& p = fs_.prims[fs_.instances[i].prim];
             if (p.kind == DP_MESH && !p.wrap) fs_.mesh_instances.push_back(i);
+        }
+        fs_.shader_bounds.assign(d_.num_shaders, 0u);
+        for (uint32_t i = 0; i < d_.num_shaders; ++i) {
+            uint32_t r = std::min<uint32_t>(count_spawns(i), RT_SHADE_MAX_SPAWN);
+            uint32_t sh = inline_points ? 0u : std::min<uint32_t>(count_phongs(i) * point_lights_, RT_SHADE_MAX_SPAWN);
+            fs_.shader_bounds[i] = r | (sh << 16);
         }
         fs_.features = f; fs_.max_ray_spawn = max_r; fs_.max_shadow_spawn = max_s; fs_.inline_point_lights = inline_points ? 1 : 0;
     }

@@ -374,8 +374,10 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                         else stream = rng_stream(rp.seed, a.list[r.slot / rp.aa_rays], 1 + r.slot % rp.aa_rays);
                     }
                     Spawn spawn[RT_SHADE_MAX_SPAWN];
-                    uint32_t nspawn;
-                    d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, spawn, nspawn, wk);
+                    ArraySink sink;
+                    sink.init(spawn);
+                    d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, sink, wk);
+                    const uint32_t nspawn = sink.n;
                     acc_contribute(la, r.slot, rw * local, a.acc, a.acc_flags);
                     for (uint32_t i = 0; i < nspawn; ++i) {
                         const Spawn& sn = spawn[i];

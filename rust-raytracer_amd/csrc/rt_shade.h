@@ -28,6 +28,57 @@ struct Spawn {            // a ray requested by the shader tree
     uint32_t shadow;      // 1: visibility test whose colour `w` counts only if nothing blocks the light
 };
 
+// Where the shader tree puts the rays it asks for.  A sink numbers rays and shadow tests
+// separately; mark() packs both counts into one word so that the interpreter can remember a
+// position and later scale the weights of everything added between two marks.
+//   ray(o, d, w, c, ordinal)     a reflected / refracted ray: weight in this hit's colour, Ray::contribution, RNG branch
+//   shadow(o, d, dist, w)        a point-light visibility test carrying that light's finished Phong term
+//   room()                       can another entry be added?
+//   scale(from, to, k)           w *= k for the entries between two marks
+struct ArraySink {        // a per-thread array, read back by the caller
+    Spawn* a;
+    uint32_t n, nrays, nshadows;
+    RT_DEV void init(Spawn* p) { a = p; n = 0; nrays = 0; nshadows = 0; }
+    RT_DEV bool room() const { return n < RT_SHADE_MAX_SPAWN; }
+    RT_DEV uint32_t mark() const { return n; }
+    RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
+        Spawn& s = a[n++]; ++nrays;
+        s.o = o; s.d = d; s.w = w; s.c = c; s.ordinal = ordinal; s.shadow = 0;
+    }
+    RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
+        Spawn& s = a[n++]; ++nshadows;
+        s.o = o; s.d = d; s.w = w; s.c = mk3(dist, 0.0, 0.0); s.ordinal = 0; s.shadow = 1;
+    }
+    RT_DEV void scale(uint32_t from, uint32_t to, d3 k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }
+    RT_DEV void scale(uint32_t from, uint32_t to, double k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }
+};
+struct QueueSink {        // straight into the next generation's queues, at positions reserved beforehand
+    LaneRay* rays;        // first reserved ray entry
+    ShadowJob* shadows;   // first reserved shadow-test entry
+    uint32_t max_rays, max_shadows, nrays, nshadows;
+    d3 parent_w;          // weight of the hit's own ray: new weights are products with it
+    uint32_t depth, parent_path, slot;
+    RT_DEV bool room() const { return true; }                      // the reservation covers the material's worst case
+    RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
+    RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
+        if (nrays >= max_rays) return;
+        LaneRay& r = rays[nrays++];
+        st3(r.o, o); st3(r.d, d); st3(r.w, parent_w * w); st3(r.c, c);
+        r.depth = depth; r.path = child_path(parent_path, ordinal); r.slot = slot; r.flags = 0u;
+    }
+    RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
+        if (nshadows >= max_shadows) return;
+        ShadowJob& s = shadows[nshadows++];
+        st3(s.o, o); st3(s.d, d); s.dist = dist; st3(s.w, parent_w * w); s.slot = slot;
+        s._pad[0] = s._pad[1] = s._pad[2] = 0;
+    }
+    template <class K>
+    RT_DEV void scale(uint32_t from, uint32_t to, K k) {
+        for (uint32_t i = from & 0xFFFFu; i < (to & 0xFFFFu); ++i) st3(rays[i].w, ld3(rays[i].w) * k);
+        for (uint32_t i = from >> 16; i < (to >> 16); ++i) st3(shadows[i].w, ld3(shadows[i].w) * k);
+    }
+};
+
 // ------------------------------------------------------------------ images
 RT_DEV d3 texel_rgb(const DScene& sc, const DImage& im, uint32_t x, uint32_t y) {   // Color::from_rgb, color.rs:78-84
     const uint8_t* p = sc.texels + im.offset + ((size_t)y * im.width + x) * 3;
@@ -186,9 +237,9 @@ RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_
 
 // PhongShader::get_color (src/shader/phong.rs:29-47).  Returns the part that is known now;
 // deferred point lights are appended to `spawn` as SHADOW entries.
-template <uint32_t F, bool COUNT>
+template <uint32_t F, bool COUNT, class SINK>
 RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, uint64_t stream, uint32_t path,
-                      Spawn* spawn, uint32_t& nspawn, Work<COUNT>& wk) {
+                      SINK& sink, Work<COUNT>& wk) {
     PhongCtx c;
     c.p = p; c.n = n; c.view = -1.0 * ray_dir;
     c.diffuse = ld3(sh.p); c.specular = ld3(sh.p + 3); c.shininess = sh.p[9];
@@ -209,12 +260,11 @@ RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_di
                     RT_COUNT(wk, shade_evals);
                     phong_lit(c, surface_dot, light_direction, intensity);
                 }
-            } else if (nspawn < RT_SHADE_MAX_SPAWN) {
+            } else if (sink.room()) {
                 PhongCtx one = c;
                 one.total = mk3(0.0, 0.0, 0.0);
                 phong_lit(one, surface_dot, light_direction, intensity);
-                Spawn& s = spawn[nspawn++];
-                s.o = p; s.d = light_direction; s.w = one.total; s.c = mk3(light_distance, 0.0, 0.0); s.ordinal = 0; s.shadow = 1;
+                sink.shadow(p, light_direction, light_distance, one.total);
             }
         } else if constexpr (F & RTF_INLINE_LIGHTS) {
             if (L.kind == 1) {
@@ -259,9 +309,9 @@ RT_DEV void fresnel(d3 d, d3 n, double ior, double& kt, double& kr) {           
 // ------------------------------------------------------------------ shader-tree interpreter
 // Walks the material of a hit depth-first, left to right — the order in which the
 // reference's nested get_color calls run — and returns L; spawned rays go to `spawn`.
-template <uint32_t F, bool COUNT>
+template <uint32_t F, bool COUNT, class SINK>
 RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit, d3 ray_dir, d3 ray_contrib,
-                    uint64_t stream, uint32_t path, Spawn* spawn, uint32_t& nspawn, Work<COUNT>& wk) {
+                    uint64_t stream, uint32_t path, SINK& sink, Work<COUNT>& wk) {
     struct Frame {
         uint32_t shader, cursor, spawn_begin, child_spawn_begin;
         d3 acc;          // MIX: running product; COMPOSITE: running sum (local parts)
@@ -271,7 +321,6 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
     Frame fr[RT_SHADE_MAX_FRAMES];
     int depth = 0;
     d3 n = hit.n;
-    nspawn = 0;
     uint32_t cur = root_shader;
     d3 cin = ray_contrib;
     d3 value = mk3(0.0, 0.0, 0.0);
@@ -280,7 +329,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         const DShader& sh = sc.shaders[cur];
         bool returned = true;
         switch (sh.kind) {
-            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, spawn, nspawn, wk); break;
+            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, sink, wk); break;
             case DS_TEXTURE:                                                                  // shader/texture.rs:16-19
                 if constexpr (F & RTF_IMAGES) value = texture_color(sc, sh.ref, hit.u, hit.v); else value = mk3(0.0, 0.0, 0.0);
                 break;
@@ -289,31 +338,22 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 break;
             case DS_REFLECTION: {                                                             // shader/reflection.rs:14-18
                 d3 k = ld3(sh.p);
-                if (nspawn < RT_SHADE_MAX_SPAWN) {
-                    Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = k; s.c = cin * k; s.ordinal = cur * 4 + 0; s.shadow = 0;
-                }
+                if (sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), k, cin * k, cur * 4 + 0);
                 value = mk3(0.0, 0.0, 0.0);
                 break;
             }
             case DS_TRANSLUCENT: {                                                            // shader/translucent.rs:50-62
                 double kt, kr;
                 fresnel(ray_dir, n, sh.p[3], kt, kr);
-                if (kt > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
-                    Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = transmit_dir(ray_dir, n, sh.p[3]); s.w = mk3(kt, kt, kt); s.c = cin * kt; s.ordinal = cur * 4 + 1; s.shadow = 0;
-                }
-                if (kr > 0.0 && nspawn < RT_SHADE_MAX_SPAWN) {
-                    Spawn& s = spawn[nspawn++];
-                    s.o = hit.p; s.d = reflect_dir(ray_dir, n); s.w = mk3(kr, kr, kr); s.c = cin * kr; s.ordinal = cur * 4 + 2; s.shadow = 0;
-                }
+                if (kt > 0.0 && sink.room()) sink.ray(hit.p, transmit_dir(ray_dir, n, sh.p[3]), mk3(kt, kt, kt), cin * kt, cur * 4 + 1);
+                if (kr > 0.0 && sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), mk3(kr, kr, kr), cin * kr, cur * 4 + 2);
                 value = mk3(0.0, 0.0, 0.0);
                 break;
             }
             default: {   // group shaders open a frame and descend into their first child
                 if (depth >= RT_SHADE_MAX_FRAMES || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
                 Frame& f = fr[depth++];
-                f.shader = cur; f.cursor = 0; f.spawn_begin = nspawn; f.child_spawn_begin = nspawn; f.cin = cin; f.saved_n = n;
+                f.shader = cur; f.cursor = 0; f.spawn_begin = sink.mark(); f.child_spawn_begin = f.spawn_begin; f.cin = cin; f.saved_n = n;
                 if (sh.kind == DS_MIX) {                                                      // shader.rs:66-69
                     f.acc = mk3(1.0, 1.0, 1.0);
                     cur = sc.shader_child_idx[sh.first_child];
@@ -343,19 +383,19 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
             const DShader& g = sc.shaders[f.shader];
             if (g.kind == DS_MIX) {
                 // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc
-                for (uint32_t i = f.spawn_begin; i < f.child_spawn_begin; ++i) spawn[i].w = spawn[i].w * value;
-                for (uint32_t i = f.child_spawn_begin; i < nspawn; ++i) spawn[i].w = spawn[i].w * f.acc;
+                sink.scale(f.spawn_begin, f.child_spawn_begin, value);
+                sink.scale(f.child_spawn_begin, sink.mark(), f.acc);
                 f.acc = f.acc * value;
             } else if (g.kind == DS_COMPOSITE) {
                 double w = sc.shader_child_weight[g.first_child + f.cursor];
-                for (uint32_t i = f.child_spawn_begin; i < nspawn; ++i) spawn[i].w = spawn[i].w * w;
+                sink.scale(f.child_spawn_begin, sink.mark(), w);
                 f.acc = f.acc + w * value;
             } else {
                 f.acc = value;
             }
             f.cursor++;
             if (g.kind != DS_CHAIN && f.cursor < g.num_children) {   // next sibling
-                f.child_spawn_begin = nspawn;
+                f.child_spawn_begin = sink.mark();
                 cur = sc.shader_child_idx[g.first_child + f.cursor];
                 cin = g.kind == DS_MIX ? f.cin * f.acc : f.cin * sc.shader_child_weight[g.first_child + f.cursor];
                 break;

@@ -137,15 +137,17 @@ k_wf_analytic(DScene sc, DRenderParams rp, WfArgs a) {
         TraceJob* job;
         if (shadow) {
             const ShadowJob& s = a.shadows[q];
-            o = ld3(s.o); d = ld3(s.d); max_distance = s.dist;
             job = a.sjobs + q;
             a.contrib[a.cap_rays + q].slot = RT_NO_SLOT;
+            if (s.slot == RT_NO_SLOT) { job->flags = 7u; continue; }        // a hole
+            o = ld3(s.o); d = ld3(s.d); max_distance = s.dist;
             RT_COUNT(wk, rays_shadow);
         } else {
             const LaneRay& r = a.rays[q];
+            job = a.rjobs + q;
+            if (r.flags & 8u) { a.contrib[q].slot = RT_NO_SLOT; job->flags = 6u; continue; }   // a hole
             o = ld3(r.o); d = ld3(r.d);
             const d3 rc = ld3(r.c);
-            job = a.rjobs + q;
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
             if (!(r.depth > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
                 WfContribution& c = a.contrib[q];
@@ -392,6 +394,10 @@ RT_DEV uint32_t wave_alloc_n(unsigned int* counter, uint32_t n) {
     return base + incl - n;
 }
 
+// A hit's new rays and shadow tests are written straight into the next generation's queues.  Room
+// for the most its material can ask for is reserved first (one atomic per wave and queue); entries
+// the hit did not use after all are marked as holes (ray flags bit 3 / shadow slot RT_NO_SLOT) and
+// cost the next generation one skipped thread each.
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
@@ -403,64 +409,58 @@ k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
     Work<COUNT> wk = {};
     for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const uint32_t q = ql >= nr ? sb + (ql - nr) : rb + ql;      // index into the shadow-test / ray arrays
-        Spawn spawn[RT_SHADE_MAX_SPAWN];
-        uint32_t nspawn = 0, nrays = 0, nshadows = 0;
-        LaneRay r;
-        d3 rw = mk3(0.0, 0.0, 0.0);
-        r.depth = 0; r.path = 0; r.slot = 0; r.flags = 0;
+        bool shade = false;
+        TraceJob j;
+        uint32_t want_rays = 0, want_shadows = 0;
         if (ql < nq) {
             if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
-                const uint32_t i = q;
-                if (!a.sjobs[i].found) {
-                    WfContribution& c = a.contrib[a.cap_rays + i];
-                    c.slot = a.shadows[i].slot;
-                    st3(c.c, ld3(a.shadows[i].w));
+                if (!(a.sjobs[q].flags & 4u) && !a.sjobs[q].found) {
+                    WfContribution& c = a.contrib[a.cap_rays + q];
+                    c.slot = a.shadows[q].slot;
+                    st3(c.c, ld3(a.shadows[q].w));
                     RT_COUNT(wk, shade_evals);
                 }
             } else {
-                const TraceJob j = a.rjobs[q];
+                j = a.rjobs[q];
                 if (!(j.flags & 4u)) {
-                    r = a.rays[q];
-                    const d3 rd = ld3(r.d);
-                    rw = ld3(r.w);
-                    WfContribution& c = a.contrib[q];
-                    c.slot = r.slot;
                     if (!j.found) {
-                        st3(c.c, rw * background_color<F>(sc, rd));
+                        const LaneRay& r = a.rays[q];
+                        WfContribution& c = a.contrib[q];
+                        c.slot = r.slot;
+                        st3(c.c, ld3(r.w) * background_color<F>(sc, ld3(r.d)));
                         if (r.flags & 1u) { a.distance[r.slot] = INFINITY; a.hit_id[r.slot] = 0xFFFFFFFFu; }
                     } else {
-                        SceneHit h;
-                        h.t = j.t; h.inst = j.inst; h.c.t = j.ct; h.c.a = j.ca; h.c.b = j.cb;
-                        WorldHit wh;
-                        world_hit<F, COUNT>(sc, ld3(r.o), rd, h, wh, wk);
-                        const DInstance& in = sc.instances[h.inst];
-                        if (r.flags & 1u) { a.distance[r.slot] = h.t; a.hit_id[r.slot] = in.node_id; }
-                        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), 0ull, r.path, spawn, nspawn, wk);
-                        st3(c.c, rw * local);
-                        for (uint32_t i = 0; i < nspawn; ++i) { if (spawn[i].shadow) ++nshadows; else ++nrays; }
+                        shade = true;
+                        const uint32_t bounds = sc.shader_bounds[sc.instances[j.inst].shader];
+                        want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
                     }
                 }
             }
         }
-        // append what the hit spawned to the next generation
-        uint32_t rbase = wave_alloc_n(a.n_out + 2 * sq, nrays);
-        uint32_t sbase = wave_alloc_n(a.n_out + 2 * sq + 1, nshadows);
-        for (uint32_t i = 0; i < nspawn; ++i) {
-            const Spawn& sn = spawn[i];
-            if (sn.shadow) {
-                if (sbase >= a.sub_shadows) { atomicAdd(a.dropped, 1u); continue; }
-                ShadowJob s;
-                st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w); s.slot = r.slot;
-                s._pad[0] = s._pad[1] = s._pad[2] = 0;
-                a.out_shadows[sb + sbase++] = s;
-            } else {
-                if (rbase >= a.sub_rays) { atomicAdd(a.dropped, 1u); continue; }
-                LaneRay nr_;
-                st3(nr_.o, sn.o); st3(nr_.d, sn.d); st3(nr_.w, rw * sn.w); st3(nr_.c, sn.c);
-                nr_.depth = r.depth - 1; nr_.path = child_path(r.path, sn.ordinal); nr_.slot = r.slot; nr_.flags = 0u;
-                a.out_rays[rb + rbase++] = nr_;
-            }
-        }
+        // room in the next generation for what the hit may ask for
+        uint32_t rbase = wave_alloc_n(a.n_out + 2 * sq, want_rays);
+        uint32_t sbase = wave_alloc_n(a.n_out + 2 * sq + 1, want_shadows);
+        if (!shade) continue;
+        if (rbase + want_rays > a.sub_rays) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub_rays ? a.sub_rays - rbase : 0u; }
+        if (sbase + want_shadows > a.sub_shadows) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub_shadows ? a.sub_shadows - sbase : 0u; }
+        const LaneRay r = a.rays[q];
+        const d3 rd = ld3(r.d), rw = ld3(r.w);
+        SceneHit h;
+        h.t = j.t; h.inst = j.inst; h.c.t = j.ct; h.c.a = j.ca; h.c.b = j.cb;
+        WorldHit wh;
+        world_hit<F, COUNT>(sc, ld3(r.o), rd, h, wh, wk);
+        const DInstance& in = sc.instances[h.inst];
+        if (r.flags & 1u) { a.distance[r.slot] = h.t; a.hit_id[r.slot] = in.node_id; }
+        QueueSink sink;
+        sink.rays = a.out_rays + rb + rbase; sink.shadows = a.out_shadows + sb + sbase;
+        sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
+        sink.parent_w = rw; sink.depth = r.depth - 1; sink.parent_path = r.path; sink.slot = r.slot;
+        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), 0ull, r.path, sink, wk);
+        WfContribution& c = a.contrib[q];
+        c.slot = r.slot;
+        st3(c.c, rw * local);
+        for (uint32_t i = sink.nrays; i < want_rays; ++i) sink.rays[i].flags = 8u;          // holes
+        for (uint32_t i = sink.nshadows; i < want_shadows; ++i) sink.shadows[i].slot = RT_NO_SLOT;
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
