@@ -69,7 +69,8 @@ struct RtScene {
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
     DeviceBuf queue[2], acc, acc_flags, lane_mem;
     // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
-    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;   // hand-over queues between rounds, split-sample accumulators
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;
+    uint32_t wf_cap = 0;   // hand-over queues between rounds, split-sample accumulators
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -432,19 +433,22 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     const uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
     WfArgs wa{};
     if (wavefront) {
-        for (auto& b : s->wf_rays) if ((e = b.ensure((size_t)wf_cap * sizeof(LaneRay))) != RT_OK) return e;
-        for (auto& b : s->wf_shadows) if ((e = b.ensure((size_t)wf_cap * sizeof(ShadowJob))) != RT_OK) return e;
-        if ((e = s->wf_rjobs.ensure((size_t)wf_cap * sizeof(TraceJob))) != RT_OK) return e;
-        if ((e = s->wf_sjobs.ensure((size_t)wf_cap * sizeof(TraceJob))) != RT_OK) return e;
-        if ((e = s->wf_contrib.ensure((size_t)wf_cap * 2 * sizeof(WfContribution))) != RT_OK) return e;
-        if ((e = s->wf_walk_list.ensure((size_t)wf_cap * 2 * sizeof(uint32_t))) != RT_OK) return e;
+        const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
+        for (auto& b : s->wf_rays) if ((e = b.ensure(n * (RQ_NF * 8 + RQ_NU * 4))) != RT_OK) return e;
+        for (auto& b : s->wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
+        if ((e = s->wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
+        if ((e = s->wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
+        if ((e = s->wf_contrib.ensure(2 * n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
+        if ((e = s->wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
         if ((e = s->wf_overflow.ensure((size_t)s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;
         if ((e = s->wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
         HIP_TRY(hipMemsetAsync(s->wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
-        wa.rjobs = (TraceJob*)s->wf_rjobs.p; wa.sjobs = (TraceJob*)s->wf_sjobs.p;
-        wa.sub_rays = wf_cap / RT_WF_Q; wa.sub_shadows = wf_cap / RT_WF_Q; wa.cap_rays = wa.sub_rays * RT_WF_Q;
+        s->wf_cap = (uint32_t)n;
+        auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
+        wa.rjobs = queue(s->wf_rjobs, n, JQ_NF); wa.sjobs = queue(s->wf_sjobs, n, JQ_NF);
+        wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
         wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min();
-        wa.contrib = (WfContribution*)s->wf_contrib.p;
+        wa.contrib = queue(s->wf_contrib, 2 * n, CQ_NF);
         wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
         wa.dropped = (unsigned int*)s->wf_scalars.p + WF_DROPPED;
@@ -457,12 +461,14 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wa.mode = mode;
         wa.list = (const uint32_t*)s->list.p;
         // generation 0 into queue set 0
-        wa.out_rays = (LaneRay*)s->wf_rays[0].p; wa.out_shadows = (ShadowJob*)s->wf_shadows[0].p; wa.n_out = ws + WF_N;
+        auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
+        const size_t n = wa.cap;
+        wa.out_rays = queue(s->wf_rays[0], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
         hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
         HIP_TRY(hipGetLastError());
         for (uint32_t g = 0; g < generations; ++g) {
-            wa.rays = (LaneRay*)s->wf_rays[g & 1].p; wa.shadows = (ShadowJob*)s->wf_shadows[g & 1].p; wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
-            wa.out_rays = (LaneRay*)s->wf_rays[(g + 1) & 1].p; wa.out_shadows = (ShadowJob*)s->wf_shadows[(g + 1) & 1].p; wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
+            wa.rays = queue(s->wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(s->wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
+            wa.out_rays = queue(s->wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
             wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g; wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g;
             int lrc = wf_launch(0, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
             if (lrc != RT_OK) return lrc;
@@ -646,7 +652,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
                 }
                 std::fprintf(stderr, "\n");
             }
-            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_rays[0].bytes / sizeof(LaneRay) / RT_WF_Q), ws[WF_DROPPED]);
+            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_cap / RT_WF_Q), ws[WF_DROPPED]);
         }
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];

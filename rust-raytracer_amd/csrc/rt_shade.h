@@ -52,32 +52,6 @@ struct ArraySink {        // a per-thread array, read back by the caller
     RT_DEV void scale(uint32_t from, uint32_t to, d3 k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }
     RT_DEV void scale(uint32_t from, uint32_t to, double k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }
 };
-struct QueueSink {        // straight into the next generation's queues, at positions reserved beforehand
-    LaneRay* rays;        // first reserved ray entry
-    ShadowJob* shadows;   // first reserved shadow-test entry
-    uint32_t max_rays, max_shadows, nrays, nshadows;
-    d3 parent_w;          // weight of the hit's own ray: new weights are products with it
-    uint32_t depth, parent_path, slot;
-    RT_DEV bool room() const { return true; }                      // the reservation covers the material's worst case
-    RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
-    RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
-        if (nrays >= max_rays) return;
-        LaneRay& r = rays[nrays++];
-        st3(r.o, o); st3(r.d, d); st3(r.w, parent_w * w); st3(r.c, c);
-        r.depth = depth; r.path = child_path(parent_path, ordinal); r.slot = slot; r.flags = 0u;
-    }
-    RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
-        if (nshadows >= max_shadows) return;
-        ShadowJob& s = shadows[nshadows++];
-        st3(s.o, o); st3(s.d, d); s.dist = dist; st3(s.w, parent_w * w); s.slot = slot;
-        s._pad[0] = s._pad[1] = s._pad[2] = 0;
-    }
-    template <class K>
-    RT_DEV void scale(uint32_t from, uint32_t to, K k) {
-        for (uint32_t i = from & 0xFFFFu; i < (to & 0xFFFFu); ++i) st3(rays[i].w, ld3(rays[i].w) * k);
-        for (uint32_t i = from >> 16; i < (to >> 16); ++i) st3(shadows[i].w, ld3(shadows[i].w) * k);
-    }
-};
 
 // ------------------------------------------------------------------ images
 RT_DEV d3 texel_rgb(const DScene& sc, const DImage& im, uint32_t x, uint32_t y) {   // Color::from_rgb, color.rs:78-84

@@ -28,34 +28,44 @@
 // holds an even sample of the frame (every 256th pixel) and stays about as long as the others.
 #define RT_WF_Q 256u
 
-struct alignas(16) WfContribution {   // one colour term for one sample
-    uint32_t slot;                    // RT_NO_SLOT: nothing
-    uint32_t _pad;
-    double c[3];
+// Queue entries are stored field by field (structure of arrays): entry e of a queue with `cap`
+// entries keeps field k at f[k*cap + e] (doubles) / u[k*cap + e] (words), so that the 64 lanes of
+// a wave, which work on consecutive entries, read and write whole cache lines per instruction.
+struct WfQueue {
+    double* f;
+    uint32_t* u;
+    RT_DEV double& F(uint32_t cap, uint32_t k, uint32_t e) const { return f[(size_t)k * cap + e]; }
+    RT_DEV uint32_t& U(uint32_t cap, uint32_t k, uint32_t e) const { return u[(size_t)k * cap + e]; }
+    RT_DEV d3 ld3(uint32_t cap, uint32_t k, uint32_t e) const { return mk3(F(cap, k, e), F(cap, k + 1, e), F(cap, k + 2, e)); }
+    RT_DEV void st3(uint32_t cap, uint32_t k, uint32_t e, d3 v) const { F(cap, k, e) = v.x; F(cap, k + 1, e) = v.y; F(cap, k + 2, e) = v.z; }
 };
+// rays (the fields of LaneRay): 12 doubles, 4 words
+enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH = 1, RQ_SLOT = 2, RQ_FLAGS = 3, RQ_NU = 4 };
+// shadow tests (ShadowJob): 10 doubles, 1 word
+enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
+// query records (TraceJob): 2 doubles, 5 words
+enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
+// colour terms: 3 doubles, 1 word (slot, RT_NO_SLOT: nothing); rays at [0, cap), shadow tests at [cap, 2 cap)
+enum { CQ_C = 0, CQ_NF = 3, CQ_SLOT = 0, CQ_NU = 1 };
 
 struct WfArgs {
-    // queries of the current generation; sub-queue s holds rays [s*sub_rays, s*sub_rays + n_in[2s]) and
-    // shadow tests [s*sub_shadows, s*sub_shadows + n_in[2s+1])
-    LaneRay* rays;
-    TraceJob* rjobs;
-    ShadowJob* shadows;
-    TraceJob* sjobs;
+    // queries of the current generation; sub-queue s holds rays [s*sub, s*sub + n_in[2s]) and
+    // shadow tests [s*sub, s*sub + n_in[2s+1]) of their arrays
+    WfQueue rays, shadows, rjobs, sjobs;
     const unsigned int* n_in;
-    uint32_t sub_rays, sub_shadows;   // capacity of one sub-queue
-    uint32_t cap_rays;                // RT_WF_Q * sub_rays
+    uint32_t sub;                     // capacity of one sub-queue
+    uint32_t cap;                     // RT_WF_Q * sub: entries per array
     // the next generation
-    LaneRay* out_rays;
-    ShadowJob* out_shadows;
+    WfQueue out_rays, out_shadows;
     unsigned int* n_out;
     // mesh walk
-    uint32_t* walk_list;              // RT_WF_Q lists of (sub_rays + sub_shadows) query ids: ray i -> i, shadow test i -> i | 0x80000000
+    uint32_t* walk_list;              // RT_WF_Q lists of 2*sub query ids: ray i -> i, shadow test i -> i | 0x80000000
     unsigned int* walk_count;         // per list
-    unsigned int* walk_next;          // per list
+    unsigned int* walk_next;          // cursor into the lists read as one
     uint32_t* walk_overflow;          // (RT_BVH_STACK - RT_WF_LDS_STACK) words per walk thread
     uint32_t refill_min;
     // outputs
-    WfContribution* contrib;          // one slot per query: rays first, shadow tests from cap_rays on
+    WfQueue contrib;                  // 2*cap entries
     unsigned long long* acc;
     uint32_t* acc_flags;
     double* distance;
@@ -68,6 +78,42 @@ struct WfArgs {
     const uint32_t* list;
     const unsigned int* aa_count;
     uint32_t mode;
+};
+
+// The shader tree's rays go straight into the next generation's queues, at positions reserved beforehand.
+struct QueueSink {
+    WfQueue rays, shadows;
+    uint32_t cap;
+    // Reserved entries: one run per lane and queue.  (Laying a wave's reservation out in planes —
+    // first new ray of every lane, then the second, ... — makes the stores denser but was measured
+    // slower overall: siblings next to each other mix long and short BVH walks within a wave.)
+    uint32_t ray0, shadow0;
+    uint32_t max_rays, max_shadows, nrays, nshadows;
+    RT_DEV uint32_t ray_entry(uint32_t k) const { return ray0 + k; }
+    RT_DEV uint32_t shadow_entry(uint32_t k) const { return shadow0 + k; }
+    d3 origin;                        // unused: every new ray starts at the hit point it is given
+    d3 parent_w;                      // weight of the hit's own ray: new weights are products with it
+    uint32_t depth, parent_path, slot;
+    RT_DEV bool room() const { return true; }                      // the reservation covers the material's worst case
+    RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
+    RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
+        if (nrays >= max_rays) return;
+        const uint32_t e = ray_entry(nrays++);
+        rays.st3(cap, RQ_O, e, o); rays.st3(cap, RQ_D, e, d); rays.st3(cap, RQ_W, e, parent_w * w); rays.st3(cap, RQ_C, e, c);
+        rays.U(cap, RQ_DEPTH, e) = depth; rays.U(cap, RQ_PATH, e) = child_path(parent_path, ordinal);
+        rays.U(cap, RQ_SLOT, e) = slot; rays.U(cap, RQ_FLAGS, e) = 0u;
+    }
+    RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
+        if (nshadows >= max_shadows) return;
+        const uint32_t e = shadow_entry(nshadows++);
+        shadows.st3(cap, SQ_O, e, o); shadows.st3(cap, SQ_D, e, d); shadows.F(cap, SQ_DIST, e) = dist;
+        shadows.st3(cap, SQ_W, e, parent_w * w); shadows.U(cap, SQ_SLOT, e) = slot;
+    }
+    template <class K>
+    RT_DEV void scale(uint32_t from, uint32_t to, K k) {
+        for (uint32_t i = from & 0xFFFFu; i < (to & 0xFFFFu); ++i) rays.st3(cap, RQ_W, ray_entry(i), rays.ld3(cap, RQ_W, ray_entry(i)) * k);
+        for (uint32_t i = from >> 16; i < (to >> 16); ++i) shadows.st3(cap, SQ_W, shadow_entry(i), shadows.ld3(cap, SQ_W, shadow_entry(i)) * k);
+    }
 };
 
 template <bool COUNT>
@@ -83,7 +129,7 @@ RT_DEV void wf_flush(DCounters* g, const Work<COUNT>& wk, unsigned long long cam
 __global__ void __launch_bounds__(256)
 k_wf_generate(DRenderParams rp, WfArgs a) {
     const uint32_t W = rp.cam.width;
-    const uint32_t total = a.mode == 0 ? W * a.num_rows : min(*a.aa_count * rp.aa_rays, a.cap_rays / 2);
+    const uint32_t total = a.mode == 0 ? W * a.num_rows : min(*a.aa_count * rp.aa_rays, a.cap / 2);
     // item i goes to sub-queue i % RT_WF_Q
     if (blockIdx.x == 0) {
         for (uint32_t sq = threadIdx.x; sq < RT_WF_Q; sq += blockDim.x) {
@@ -111,11 +157,12 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
             dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
             slot = item;
         }
-        LaneRay r;
-        st3(r.o, cam_o); st3(r.d, dir);
-        st3(r.w, mk3(1.0, 1.0, 1.0)); st3(r.c, mk3(1.0, 1.0, 1.0));
-        r.depth = rp.recursion_depth; r.path = 1u; r.slot = slot; r.flags = a.mode == 0 ? 3u : 2u;
-        a.out_rays[(size_t)(item % RT_WF_Q) * a.sub_rays + item / RT_WF_Q] = r;
+        const uint32_t e = (item % RT_WF_Q) * a.sub + item / RT_WF_Q;
+        const WfQueue& r = a.out_rays;
+        r.st3(a.cap, RQ_O, e, cam_o); r.st3(a.cap, RQ_D, e, dir);
+        r.st3(a.cap, RQ_W, e, mk3(1.0, 1.0, 1.0)); r.st3(a.cap, RQ_C, e, mk3(1.0, 1.0, 1.0));
+        r.U(a.cap, RQ_DEPTH, e) = rp.recursion_depth; r.U(a.cap, RQ_PATH, e) = 1u;
+        r.U(a.cap, RQ_SLOT, e) = slot; r.U(a.cap, RQ_FLAGS, e) = a.mode == 0 ? 3u : 2u;
     }
 }
 
@@ -125,57 +172,51 @@ __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene sc, DRenderParams rp, WfArgs a) {
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
-    const uint32_t nr = min(a.n_in[2 * sq], a.sub_rays), nsh = min(a.n_in[2 * sq + 1], a.sub_shadows);
-    const uint32_t rbase = sq * a.sub_rays, sbase = sq * a.sub_shadows;
+    const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
+    const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
     for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const bool shadow = ql >= nr;
-        const uint32_t q = shadow ? sbase + (ql - nr) : rbase + ql;   // index into the shadow-test / ray arrays
+        const uint32_t q = sq * a.sub + (shadow ? ql - nr : ql);      // entry of the shadow-test / ray arrays
+        const WfQueue& jobs = shadow ? a.sjobs : a.rjobs;
         d3 o, d;
         double max_distance = 0.0;
-        TraceJob* job;
         if (shadow) {
-            const ShadowJob& s = a.shadows[q];
-            job = a.sjobs + q;
-            a.contrib[a.cap_rays + q].slot = RT_NO_SLOT;
-            if (s.slot == RT_NO_SLOT) { job->flags = 7u; continue; }        // a hole
-            o = ld3(s.o); d = ld3(s.d); max_distance = s.dist;
+            a.contrib.U(2 * cap, CQ_SLOT, cap + q) = RT_NO_SLOT;
+            if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { jobs.U(cap, JQ_FLAGS, q) = 7u; continue; }        // a hole
+            o = a.shadows.ld3(cap, SQ_O, q); d = a.shadows.ld3(cap, SQ_D, q); max_distance = a.shadows.F(cap, SQ_DIST, q);
             RT_COUNT(wk, rays_shadow);
         } else {
-            const LaneRay& r = a.rays[q];
-            job = a.rjobs + q;
-            if (r.flags & 8u) { a.contrib[q].slot = RT_NO_SLOT; job->flags = 6u; continue; }   // a hole
-            o = ld3(r.o); d = ld3(r.d);
-            const d3 rc = ld3(r.c);
+            const uint32_t flags = a.rays.U(cap, RQ_FLAGS, q);
+            if (flags & 8u) { a.contrib.U(2 * cap, CQ_SLOT, q) = RT_NO_SLOT; jobs.U(cap, JQ_FLAGS, q) = 6u; continue; }   // a hole
+            o = a.rays.ld3(cap, RQ_O, q); d = a.rays.ld3(cap, RQ_D, q);
+            const d3 rc = a.rays.ld3(cap, RQ_C, q);
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
-            if (!(r.depth > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
-                WfContribution& c = a.contrib[q];
-                c.slot = r.slot;
-                st3(c.c, ld3(r.w) * background_color<F>(sc, d));
-                if (r.flags & 1u) { a.distance[r.slot] = INFINITY; a.hit_id[r.slot] = 0xFFFFFFFFu; }
-                job->flags = 6u;
+            if (!(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
+                const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
+                a.contrib.U(2 * cap, CQ_SLOT, q) = slot;
+                a.contrib.st3(2 * cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, d));
+                if (flags & 1u) { a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
+                jobs.U(cap, JQ_FLAGS, q) = 6u;
                 continue;
             }
-            a.contrib[q].slot = RT_NO_SLOT;
-            if (COUNT) { if (r.flags & 2u) cam++; else wk.rays_secondary++; }
+            a.contrib.U(2 * cap, CQ_SLOT, q) = RT_NO_SLOT;
+            if (COUNT) { if (flags & 2u) cam++; else wk.rays_secondary++; }
         }
         SceneHit h;
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         bool found = trace_scene<F, COUNT, HAS_MESH>(sc, o, d, shadow, max_distance, h, wk);
-        TraceJob j;
-        j.t = shadow ? max_distance : h.t;
-        j.inst = h.inst; j.found = found ? 1u : 0u;
-        j.ct = h.c.t; j.ca = h.c.a; j.cb = h.c.b;
-        j.src = 0;
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
-        j.flags = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
-        j._pad[0] = 0; j._pad[1] = 0;
-        *job = j;
+        jobs.F(cap, JQ_T, q) = shadow ? max_distance : h.t;
+        jobs.F(cap, JQ_CT, q) = h.c.t;
+        jobs.U(cap, JQ_INST, q) = h.inst; jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
+        jobs.U(cap, JQ_CA, q) = h.c.a; jobs.U(cap, JQ_CB, q) = h.c.b;
+        jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
         if constexpr (HAS_MESH) {
             if (!settled && sc.num_mesh_instances > 0) {
                 uint32_t w = wave_alloc(a.walk_count + sq);
-                a.walk_list[(size_t)sq * (a.sub_rays + a.sub_shadows) + w] = shadow ? (q | 0x80000000u) : q;
+                a.walk_list[(size_t)sq * (2u * a.sub) + w] = shadow ? (q | 0x80000000u) : q;
             }
         }
     }
@@ -200,7 +241,7 @@ k_wf_walk(DScene sc, WfArgs a) {
     if (threadIdx.x < 64) {                                          // exclusive scan of the list lengths by the first wave
         uint32_t run = 0;
         for (uint32_t base = 0; base < RT_WF_Q; base += 64) {
-            uint32_t n = min(a.walk_count[base + threadIdx.x], a.sub_rays + a.sub_shadows);
+            uint32_t n = min(a.walk_count[base + threadIdx.x], 2u * a.sub);
             uint32_t incl = n;
             for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
             starts[base + threadIdx.x] = run + incl - n;
@@ -225,8 +266,9 @@ k_wf_walk(DScene sc, WfArgs a) {
     uint32_t chunk_next = 0, chunk_end = 0;                          // the wave's reserved part of the joint list
     bool dry = total == 0;                                           // wave-uniform: the joint list is used up
     bool have = false, walking = false;
-    TraceJob* q = nullptr;
-    const double* od = nullptr;
+    uint32_t qe = 0;                                                 // the query's entry in its arrays
+    bool qshadow = false;
+    d3 qo = mk3(0.0, 0.0, 0.0), qd = qo;                             // its ray, world space
     uint32_t m = 0;
     double qt = 0.0, qct = 0.0;
     uint32_t qinst = 0, qfound = 0, qca = 0;
@@ -251,7 +293,10 @@ k_wf_walk(DScene sc, WfArgs a) {
         return sp < RT_WF_LDS_STACK ? lstack[sp * lstride] : gstack[sp - RT_WF_LDS_STACK];
     };
     auto finish_query = [&]() {
-        q->t = qt; q->inst = qinst; q->found = qfound; q->ct = qct; q->ca = qca; q->cb = 0u;
+        const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
+        jobs.F(a.cap, JQ_T, qe) = qt; jobs.F(a.cap, JQ_CT, qe) = qct;
+        jobs.U(a.cap, JQ_INST, qe) = qinst; jobs.U(a.cap, JQ_FOUND, qe) = qfound;
+        jobs.U(a.cap, JQ_CA, qe) = qca; jobs.U(a.cap, JQ_CB, qe) = 0u;
         have = false;
     };
     for (;;) {
@@ -280,11 +325,15 @@ k_wf_walk(DScene sc, WfArgs a) {
                     // which list does joint entry idx belong to?  (largest l with starts[l] <= idx)
                     uint32_t lo = 0, hi = RT_WF_Q;
                     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= idx) lo = mid; else hi = mid; }
-                    const uint32_t e = a.walk_list[(size_t)lo * (a.sub_rays + a.sub_shadows) + (idx - starts[lo])];
-                    if (e & 0x80000000u) { q = a.sjobs + (e & 0x7FFFFFFFu); od = a.shadows[e & 0x7FFFFFFFu].o; }
-                    else { q = a.rjobs + e; od = a.rays[e].o; }
-                    any = (q->flags & 1u) != 0;
-                    qt = q->t; qinst = q->inst; qfound = q->found; qct = q->ct; qca = q->ca;
+                    const uint32_t e = a.walk_list[(size_t)lo * (2u * a.sub) + (idx - starts[lo])];
+                    qshadow = (e & 0x80000000u) != 0;
+                    qe = e & 0x7FFFFFFFu;
+                    if (qshadow) { qo = a.shadows.ld3(a.cap, SQ_O, qe); qd = a.shadows.ld3(a.cap, SQ_D, qe); }
+                    else { qo = a.rays.ld3(a.cap, RQ_O, qe); qd = a.rays.ld3(a.cap, RQ_D, qe); }
+                    const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
+                    any = qshadow;
+                    qt = jobs.F(a.cap, JQ_T, qe); qct = jobs.F(a.cap, JQ_CT, qe);
+                    qinst = jobs.U(a.cap, JQ_INST, qe); qfound = jobs.U(a.cap, JQ_FOUND, qe); qca = jobs.U(a.cap, JQ_CA, qe);
                     have = true; m = 0;
                 }
             }
@@ -294,7 +343,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                     const DInstance& in = sc.instances[inst];
                     const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
                     double s;
-                    lr = to_local(in.x, ld3(od), ld3(od + 3), s, inv_s);
+                    lr = to_local(in.x, qo, qd, s, inv_s);
                     RT_COUNT(wk, instance_tests);
                     inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
                     tmax = qt * s;
@@ -375,23 +424,23 @@ k_wf_walk(DScene sc, WfArgs a) {
 }
 
 // ------------------------------------------------------------------ shading phase
-// Room for `n` consecutive entries per calling lane in a queue; one atomic per wave.
-RT_DEV uint32_t wave_alloc_n(unsigned int* counter, uint32_t n) {
-    // inclusive scan of n over the active lanes
+// Room for `nr` consecutive ray entries and `ns` consecutive shadow-test entries per calling lane;
+// both fill counters share one 64-bit word (rays low, shadow tests high) so that one atomic per
+// wave serves both queues.  Every lane of the wave must call (with zeros if it wants nothing).
+RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32_t& rbase, uint32_t& sbase) {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long active = __ballot(1);
-    uint32_t incl = n;
+    unsigned long long incl = (unsigned long long)nr | ((unsigned long long)ns << 32);
+    const unsigned long long mine = incl;
     for (int off = 1; off < 64; off <<= 1) {
-        uint32_t v = __shfl_up(incl, off);
+        unsigned long long v = __shfl_up(incl, off);
         if ((int)lane >= off) incl += v;
     }
-    // inactive lanes hand on garbage in the scan: every caller passes n = 0 for lanes without a request instead of leaving the call
-    const uint32_t last = 63u - (uint32_t)__builtin_clzll(active);
-    const uint32_t sum = __shfl(incl, last);
-    uint32_t base = 0;
-    if (lane == last && sum) base = atomicAdd(counter, sum);
-    base = __shfl(base, last);
-    return base + incl - n;
+    const unsigned long long sum = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 63u && sum) base = atomicAdd(reinterpret_cast<unsigned long long*>(counters), sum);
+    base = __shfl(base, 63);
+    const unsigned long long at = base + incl - mine;
+    rbase = (uint32_t)at; sbase = (uint32_t)(at >> 32);
 }
 
 // A hit's new rays and shadow tests are written straight into the next generation's queues.  Room
@@ -402,65 +451,62 @@ template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
     const uint32_t sq = blockIdx.x % RT_WF_Q;
-    const uint32_t nr = min(a.n_in[2 * sq], a.sub_rays), nsh = min(a.n_in[2 * sq + 1], a.sub_shadows);
-    const uint32_t rb = sq * a.sub_rays, sb = sq * a.sub_shadows;
+    const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
+    const uint32_t cap = a.cap;
     const uint32_t nq = nr + nsh;
     const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: the queue allocation is a wave operation
     Work<COUNT> wk = {};
     for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
-        const uint32_t q = ql >= nr ? sb + (ql - nr) : rb + ql;      // index into the shadow-test / ray arrays
+        const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
         bool shade = false;
-        TraceJob j;
-        uint32_t want_rays = 0, want_shadows = 0;
+        uint32_t want_rays = 0, want_shadows = 0, inst = 0;
         if (ql < nq) {
             if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
-                if (!(a.sjobs[q].flags & 4u) && !a.sjobs[q].found) {
-                    WfContribution& c = a.contrib[a.cap_rays + q];
-                    c.slot = a.shadows[q].slot;
-                    st3(c.c, ld3(a.shadows[q].w));
+                if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
+                    a.contrib.U(2 * cap, CQ_SLOT, cap + q) = a.shadows.U(cap, SQ_SLOT, q);
+                    a.contrib.st3(2 * cap, CQ_C, cap + q, a.shadows.ld3(cap, SQ_W, q));
                     RT_COUNT(wk, shade_evals);
                 }
-            } else {
-                j = a.rjobs[q];
-                if (!(j.flags & 4u)) {
-                    if (!j.found) {
-                        const LaneRay& r = a.rays[q];
-                        WfContribution& c = a.contrib[q];
-                        c.slot = r.slot;
-                        st3(c.c, ld3(r.w) * background_color<F>(sc, ld3(r.d)));
-                        if (r.flags & 1u) { a.distance[r.slot] = INFINITY; a.hit_id[r.slot] = 0xFFFFFFFFu; }
-                    } else {
-                        shade = true;
-                        const uint32_t bounds = sc.shader_bounds[sc.instances[j.inst].shader];
-                        want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
-                    }
+            } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
+                if (!a.rjobs.U(cap, JQ_FOUND, q)) {
+                    const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
+                    a.contrib.U(2 * cap, CQ_SLOT, q) = slot;
+                    a.contrib.st3(2 * cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q)));
+                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
+                } else {
+                    shade = true;
+                    inst = a.rjobs.U(cap, JQ_INST, q);
+                    const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
+                    want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
                 }
             }
         }
         // room in the next generation for what the hit may ask for
-        uint32_t rbase = wave_alloc_n(a.n_out + 2 * sq, want_rays);
-        uint32_t sbase = wave_alloc_n(a.n_out + 2 * sq + 1, want_shadows);
+        uint32_t rbase, sbase;
+        wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
         if (!shade) continue;
-        if (rbase + want_rays > a.sub_rays) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub_rays ? a.sub_rays - rbase : 0u; }
-        if (sbase + want_shadows > a.sub_shadows) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub_shadows ? a.sub_shadows - sbase : 0u; }
-        const LaneRay r = a.rays[q];
-        const d3 rd = ld3(r.d), rw = ld3(r.w);
-        SceneHit h;
-        h.t = j.t; h.inst = j.inst; h.c.t = j.ct; h.c.a = j.ca; h.c.b = j.cb;
-        WorldHit wh;
-        world_hit<F, COUNT>(sc, ld3(r.o), rd, h, wh, wk);
-        const DInstance& in = sc.instances[h.inst];
-        if (r.flags & 1u) { a.distance[r.slot] = h.t; a.hit_id[r.slot] = in.node_id; }
+        if (rbase + want_rays > a.sub) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub ? a.sub - rbase : 0u; }
+        if (sbase + want_shadows > a.sub) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub ? a.sub - sbase : 0u; }
         QueueSink sink;
-        sink.rays = a.out_rays + rb + rbase; sink.shadows = a.out_shadows + sb + sbase;
+        sink.ray0 = sq * a.sub + rbase; sink.shadow0 = sq * a.sub + sbase;
+        const d3 ro = a.rays.ld3(cap, RQ_O, q), rd = a.rays.ld3(cap, RQ_D, q), rw = a.rays.ld3(cap, RQ_W, q), rc = a.rays.ld3(cap, RQ_C, q);
+        const uint32_t rdepth = a.rays.U(cap, RQ_DEPTH, q), rpath = a.rays.U(cap, RQ_PATH, q);
+        const uint32_t rslot = a.rays.U(cap, RQ_SLOT, q), rflags = a.rays.U(cap, RQ_FLAGS, q);
+        SceneHit h;
+        h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
+        h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
+        WorldHit wh;
+        world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
+        const DInstance& in = sc.instances[inst];
+        if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
+        sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
         sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
-        sink.parent_w = rw; sink.depth = r.depth - 1; sink.parent_path = r.path; sink.slot = r.slot;
-        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), 0ull, r.path, sink, wk);
-        WfContribution& c = a.contrib[q];
-        c.slot = r.slot;
-        st3(c.c, rw * local);
-        for (uint32_t i = sink.nrays; i < want_rays; ++i) sink.rays[i].flags = 8u;          // holes
-        for (uint32_t i = sink.nshadows; i < want_shadows; ++i) sink.shadows[i].slot = RT_NO_SLOT;
+        sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot;
+        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
+        a.contrib.U(2 * cap, CQ_SLOT, q) = rslot;
+        a.contrib.st3(2 * cap, CQ_C, q, rw * local);
+        for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
+        for (uint32_t i = sink.nshadows; i < want_shadows; ++i) a.out_shadows.U(cap, SQ_SLOT, sink.shadow_entry(i)) = RT_NO_SLOT;
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
@@ -471,15 +517,15 @@ k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
 __global__ void __launch_bounds__(256)
 k_wf_accumulate(WfArgs a) {
     const uint32_t sq = blockIdx.x % RT_WF_Q;
-    const uint32_t nr = min(a.n_in[2 * sq], a.sub_rays), nsh = min(a.n_in[2 * sq + 1], a.sub_shadows);
+    const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t tasks = (nr + nsh) * RT_ACC_LIMBS;
     for (uint32_t t = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; t < tasks; t += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const uint32_t ql = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
-        const WfContribution& c = a.contrib[ql < nr ? (size_t)sq * a.sub_rays + ql : (size_t)a.cap_rays + (size_t)sq * a.sub_shadows + (ql - nr)];
-        const uint32_t slot = c.slot;
+        const uint32_t e = ql < nr ? sq * a.sub + ql : a.cap + sq * a.sub + (ql - nr);
+        const uint32_t slot = a.contrib.U(2 * a.cap, CQ_SLOT, e);
         if (slot == RT_NO_SLOT) continue;
         const uint32_t channel = limb / 3u, part = limb % 3u;
-        const double v = c.c[channel];
+        const double v = a.contrib.F(2 * a.cap, CQ_C + channel, e);
         if (!(fabs(v) < 0x1p40)) {
             if (part == 0) {
                 uint32_t bit = (v != v) ? 4u : (v > 0.0 ? 1u : 2u);

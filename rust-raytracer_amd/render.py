@@ -10,7 +10,7 @@ import numpy as np
 from ._abi import RT_OK, RtAux, RtCamera, RtImageDim, RtRenderConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "csrc", "librt_amd.so")
+HIP_LIB = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")   # RT_AMD_LIB: another build of the same library (kernel tuning experiments)
 
 EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
            "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings"]
