@@ -256,10 +256,12 @@ constexpr uint32_t WF_N = 0, WF_WALK_COUNT = WF_N + 2 * RT_WF_Q * (WF_MAX_GEN + 
                    WF_PASS_WORDS = WF_WALK_NEXT + RT_WF_Q * (WF_MAX_GEN + 1);
 constexpr uint32_t WF_DROPPED = 2 * WF_PASS_WORDS;
 constexpr size_t WF_SCALAR_BYTES = (WF_DROPPED + 4) * 4;
+// RT_PATH=persistent forces the persistent kernel for every scene (read at every frame, so that a
+// test can render the same scene down both schedules in one process).
 bool use_wavefront(uint32_t features) {
-    static const int forced = [] { const char* e = std::getenv("RT_PATH"); return !e ? 0 : (std::strcmp(e, "persistent") == 0 ? 1 : (std::strcmp(e, "queues") == 0 ? 2 : 0)); }();
     if (features & RTF_INLINE_LIGHTS) return false;      // visibility inside the shader: persistent kernel only
-    return forced != 1;
+    const char* e = std::getenv("RT_PATH");
+    return !(e && std::strcmp(e, "persistent") == 0);
 }
 
 // Layout of the per-frame scalar block (u32 words), zeroed at the start of every frame.

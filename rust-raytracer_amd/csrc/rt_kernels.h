@@ -375,7 +375,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                     }
                     Spawn spawn[RT_SHADE_MAX_SPAWN];
                     ArraySink sink;
-                    sink.init(spawn);
+                    sink.init(spawn, rw);
                     d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, sink, wk);
                     const uint32_t nspawn = sink.n;
                     acc_contribute(la, r.slot, rw * local, a.acc, a.acc_flags);
@@ -385,11 +385,11 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                             if (ns >= RT_MAX_SHADOW_JOBS) { RT_COUNT(wk, stack_overflows); continue; }
                             ShadowJob& s = shadows[(sh_head + ns) % RT_MAX_SHADOW_JOBS];
                             ++ns;
-                            st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, rw * sn.w); s.slot = r.slot;
+                            st3(s.o, sn.o); st3(s.d, sn.d); s.dist = sn.c.x; st3(s.w, sn.w); s.slot = r.slot;
                         } else {
                             // the first new ray takes over its parent's slot, the others go on top
                             LaneRay nr;
-                            st3(nr.o, sn.o); st3(nr.d, sn.d); st3(nr.w, rw * sn.w); st3(nr.c, sn.c);
+                            st3(nr.o, sn.o); st3(nr.d, sn.d); st3(nr.w, sn.w); st3(nr.c, sn.c);
                             nr.depth = r.depth - 1; nr.path = child_path(r.path, sn.ordinal); nr.slot = r.slot; nr.flags = 0u;
                             if (!reused) { stack[slot] = nr; reused = true; }
                             else if (top < RT_MAX_STACK) stack[top++] = nr;

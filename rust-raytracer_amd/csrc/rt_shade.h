@@ -22,7 +22,7 @@
 
 struct Spawn {            // a ray requested by the shader tree
     d3 o, d;
-    d3 w;                 // RAY: multiplies the ray's colour in this hit's colour; SHADOW: the light's Phong term
+    d3 w;                 // weight of the new ray's colour in the sample (RAY) / colour added to the sample if the light is visible (SHADOW)
     d3 c;                 // RAY: Ray::contribution of the new ray (ray.rs:22-26); SHADOW: c.x = distance to the light
     uint32_t ordinal;     // RAY: identifies the spawning shader + branch for the RNG path
     uint32_t shadow;      // 1: visibility test whose colour `w` counts only if nothing blocks the light
@@ -35,19 +35,22 @@ struct Spawn {            // a ray requested by the shader tree
 //   shadow(o, d, dist, w)        a point-light visibility test carrying that light's finished Phong term
 //   room()                       can another entry be added?
 //   scale(from, to, k)           w *= k for the entries between two marks
+// Both sinks multiply a new weight by the weight of the hit's own ray first and apply group-shader
+// factors (scale) afterwards, so that the two schedules of the trace round identically.
 struct ArraySink {        // a per-thread array, read back by the caller
     Spawn* a;
     uint32_t n, nrays, nshadows;
-    RT_DEV void init(Spawn* p) { a = p; n = 0; nrays = 0; nshadows = 0; }
+    d3 parent_w;
+    RT_DEV void init(Spawn* p, d3 pw) { a = p; n = 0; nrays = 0; nshadows = 0; parent_w = pw; }
     RT_DEV bool room() const { return n < RT_SHADE_MAX_SPAWN; }
     RT_DEV uint32_t mark() const { return n; }
     RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
         Spawn& s = a[n++]; ++nrays;
-        s.o = o; s.d = d; s.w = w; s.c = c; s.ordinal = ordinal; s.shadow = 0;
+        s.o = o; s.d = d; s.w = parent_w * w; s.c = c; s.ordinal = ordinal; s.shadow = 0;
     }
     RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
         Spawn& s = a[n++]; ++nshadows;
-        s.o = o; s.d = d; s.w = w; s.c = mk3(dist, 0.0, 0.0); s.ordinal = 0; s.shadow = 1;
+        s.o = o; s.d = d; s.w = parent_w * w; s.c = mk3(dist, 0.0, 0.0); s.ordinal = 0; s.shadow = 1;
     }
     RT_DEV void scale(uint32_t from, uint32_t to, d3 k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }
     RT_DEV void scale(uint32_t from, uint32_t to, double k) { for (uint32_t i = from; i < to; ++i) a[i].w = a[i].w * k; }

@@ -200,3 +200,24 @@ def test_device_entry_point_and_gather_assembly(device_scene, scene_cache, rende
         parts.append(buf)
     torch.cuda.synchronize()
     assert np.array_equal(rdist.assemble(torch.stack(parts), 180, 2, 16).cpu().numpy(), want)
+
+
+# ---- the two schedules of the trace (queue pipeline / persistent kernel) are the same arithmetic ----
+@pytest.mark.parametrize("name,width", [("glass_monkey", 256), ("many_balls", 160), ("subtraction_outside1", 160),
+                                        ("mesh_basic", 128), ("primitive_zoo", 128), ("refraction_03", 128)])
+def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatch):
+    s = scene_cache(name)
+    ds = device_scene(name)
+    dim, cam, cfg = small_view(s, width, anti_alias=True, seed=1)
+    monkeypatch.delenv("RT_PATH", raising=False)
+    a = ds.render(dim, cam, cfg, count_work=True)
+    monkeypatch.setenv("RT_PATH", "persistent")
+    b = ds.render(dim, cam, cfg, count_work=True)
+    monkeypatch.delenv("RT_PATH", raising=False)
+    # colours are sums of the same terms in fixed point: identical to the last bit, whatever the order
+    assert np.array_equal(a["color"], b["color"]), name
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit_id"], b["hit_id"])
+    assert np.array_equal(a["distance"], b["distance"]) and np.array_equal(a["aa_mask"], b["aa_mask"])
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_aa", "shade_evals", "tri_tests", "stack_overflows"):
+        assert a["counters"][k] == b["counters"][k], (name, k)
+    assert a["counters"]["stack_overflows"] == 0
