@@ -11,9 +11,11 @@ prints one JSON line.
 
 ray        = one closest-hit query that passed the depth/contribution gate, or one any-hit
              shadow query (counted on device by an instrumented, untimed frame)
-roofline   = FP64 vector ALU: algorithmic flops of the dominant kernel (fixed cost per
-             counted unit of work, see fill_counters in csrc/rt_api.hip) / its HIP-event
-             duration, against the 78.6 TFLOP/s FP64 vector peak
+roofline   = FP64 vector ALU: algorithmic flops (fixed cost per counted unit of work, see
+             fill_counters in csrc/rt_api.hip) of the longer of the two trace passes / its
+             HIP-event duration, against the 78.6 TFLOP/s FP64 vector peak.  A pass is one
+             launch sequence of the queue pipeline (analytic / BVH walk / shade / accumulate
+             per ray generation); the events bracket the whole sequence on the launch stream
 cpu_baseline = the CPU restatement of the reference (oracle/, 8 threads like the
              reference's default pool) on a bounded sample of the same frame
 """
@@ -143,9 +145,9 @@ def main():
             stage_ms[k] /= args.steps
         # dominant kernel of rank 0's share
         if stage_ms["aa"] >= stage_ms["pass1"]:
-            kernel, k_ms, k_flops = "k_trace (AA resolve launch)", stage_ms["aa"], flops_aa
+            kernel, k_ms, k_flops = "AA-resolve pass (k_wf_analytic + k_wf_walk + k_wf_shade + k_wf_accumulate per generation)", stage_ms["aa"], flops_aa
         else:
-            kernel, k_ms, k_flops = "k_trace (pass-1 launch)", stage_ms["pass1"], flops_pass1
+            kernel, k_ms, k_flops = "pass 1 (k_wf_analytic + k_wf_walk + k_wf_shade + k_wf_accumulate per generation)", stage_ms["pass1"], flops_pass1
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         fb_bytes = WIDTH * HEIGHT * (32 + 3)   # f64 colour+distance written once, RGB8 written once
         out = {

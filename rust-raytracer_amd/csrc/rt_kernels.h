@@ -375,7 +375,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
                     }
                     Spawn spawn[RT_SHADE_MAX_SPAWN];
                     ArraySink sink;
-                    sink.init(spawn, rw);
+                    sink.init(spawn, rw, r.depth - 1, sc.has_background == 0);
                     d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, ld3(r.c), stream, r.path, sink, wk);
                     const uint32_t nspawn = sink.n;
                     acc_contribute(la, r.slot, rw * local, a.acc, a.acc_flags);

@@ -41,10 +41,13 @@ struct ArraySink {        // a per-thread array, read back by the caller
     Spawn* a;
     uint32_t n, nrays, nshadows;
     d3 parent_w;
-    RT_DEV void init(Spawn* p, d3 pw) { a = p; n = 0; nrays = 0; nshadows = 0; parent_w = pw; }
+    uint32_t child_depth;     // Ray::depth of the rays spawned here
+    bool drop_dead;           // scene without a sky box: a ray that will fail the gate of Scene::cast_ray adds exactly nothing
+    RT_DEV void init(Spawn* p, d3 pw, uint32_t depth, bool drop) { a = p; n = 0; nrays = 0; nshadows = 0; parent_w = pw; child_depth = depth; drop_dead = drop; }
     RT_DEV bool room() const { return n < RT_SHADE_MAX_SPAWN; }
     RT_DEV uint32_t mark() const { return n; }
     RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
+        if (drop_dead && !(child_depth > 0 && (c.x + c.y + c.z) > RT_MIN_CONTRIBUTION)) return;   // scene.rs:67-73 with a BLACK background
         Spawn& s = a[n++]; ++nrays;
         s.o = o; s.d = d; s.w = parent_w * w; s.c = c; s.ordinal = ordinal; s.shadow = 0;
     }

@@ -94,9 +94,11 @@ struct QueueSink {
     d3 origin;                        // unused: every new ray starts at the hit point it is given
     d3 parent_w;                      // weight of the hit's own ray: new weights are products with it
     uint32_t depth, parent_path, slot;
+    bool drop_dead;                   // scene without a sky box: a ray that will fail the gate of Scene::cast_ray adds exactly nothing
     RT_DEV bool room() const { return true; }                      // the reservation covers the material's worst case
     RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
     RT_DEV void ray(d3 o, d3 d, d3 w, d3 c, uint32_t ordinal) {
+        if (drop_dead && !(depth > 0 && (c.x + c.y + c.z) > RT_MIN_CONTRIBUTION)) return;   // scene.rs:67-73 with a BLACK background
         if (nrays >= max_rays) return;
         const uint32_t e = ray_entry(nrays++);
         rays.st3(cap, RQ_O, e, o); rays.st3(cap, RQ_D, e, d); rays.st3(cap, RQ_W, e, parent_w * w); rays.st3(cap, RQ_C, e, c);
@@ -501,7 +503,7 @@ k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
         if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
         sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
         sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
-        sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot;
+        sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0;
         d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
         a.contrib.U(2 * cap, CQ_SLOT, q) = rslot;
         a.contrib.st3(2 * cap, CQ_C, q, rw * local);
