@@ -126,14 +126,30 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
     DScene& d = s->ds;
-    int rc = RT_OK;
+    // the small tables back to back in one allocation (16-byte aligned sections), the big ones on their own
+    std::vector<uint8_t> hot;
+    std::vector<std::pair<const void**, size_t>> hot_fix;   // (pointer field, offset into `hot`)
+    auto pack = [&](const void* data, size_t bytes, const void** field) {
+        *field = nullptr;
+        if (bytes == 0) return;
+        while (hot.size() % 16) hot.push_back(0);
+        hot_fix.emplace_back(field, hot.size());
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        hot.insert(hot.end(), p, p + bytes);
+    };
+#define HOT(field, vec) pack(vec.data(), vec.size() * sizeof(vec[0]), reinterpret_cast<const void**>(&d.field))
+    HOT(instances, fs.instances); HOT(mesh_instances, fs.mesh_instances); HOT(prims, fs.prims); HOT(tris, fs.tris); HOT(polys, fs.polys);
+    HOT(points, fs.points); HOT(faced, fs.faced); HOT(meshes, fs.meshes); HOT(csg_roots, fs.csg_roots); HOT(csg_ops, fs.csg_ops);
+    HOT(csg_leaves, fs.csg_leaves); HOT(shaders, fs.shaders); HOT(shader_bounds, fs.shader_bounds); HOT(shader_child_idx, fs.shader_child_idx);
+    HOT(shader_child_weight, fs.shader_child_weight); HOT(chain_nmaps, fs.chain_nmaps); HOT(normal_maps, fs.normal_maps);
+    HOT(images, fs.images); HOT(gamma_lut, fs.gamma_lut); HOT(lights, fs.lights);
+#undef HOT
+    while (hot.size() % 16) hot.push_back(0);
+    int rc = upload(hot, s->owned, &d.hot_blob);
+    for (auto& f : hot_fix) *f.first = d.hot_blob + f.second;
+    d.hot_bytes = hot.size() <= RT_HOT_LIMIT ? (uint32_t)hot.size() : 0u;
 #define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
-    UP(instances, fs.instances); UP(mesh_instances, fs.mesh_instances); UP(prims, fs.prims); UP(tris, fs.tris); UP(polys, fs.polys); UP(points, fs.points);
-    UP(faced, fs.faced); UP(meshes, fs.meshes); UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris);
-    UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(csg_roots, fs.csg_roots); UP(csg_ops, fs.csg_ops);
-    UP(csg_leaves, fs.csg_leaves); UP(shaders, fs.shaders); UP(shader_bounds, fs.shader_bounds); UP(shader_child_idx, fs.shader_child_idx);
-    UP(shader_child_weight, fs.shader_child_weight); UP(chain_nmaps, fs.chain_nmaps); UP(normal_maps, fs.normal_maps);
-    UP(images, fs.images); UP(texels, fs.texels); UP(gamma_lut, fs.gamma_lut); UP(lights, fs.lights);
+    UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(texels, fs.texels);
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
     d.num_instances = (uint32_t)fs.instances.size();
@@ -209,12 +225,13 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 // ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
+    const uint32_t lds = ds.hot_bytes;   // the scene's small tables
     if (which == 0) {
-        if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
-        else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+        if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
+        else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
     } else {
-        if (count) hipLaunchKernelGGL((k_wf_shade<F, true>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
-        else hipLaunchKernelGGL((k_wf_shade<F, false>), dim3(grid), dim3(256), 0, stream, ds, rp, wa);
+        if (count) hipLaunchKernelGGL((k_wf_shade<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
+        else hipLaunchKernelGGL((k_wf_shade<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));

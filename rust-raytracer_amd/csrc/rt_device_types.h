@@ -18,6 +18,7 @@
 #define RT_BATCH 8             // most scene queries (shadow tests + rays off the stack) a lane runs per trip
 #define RT_BVH_STACK 48        // BVH traversal stack entries (deeper trees are rejected at scene creation)
 #define RT_LDS_STACK 16        // ... of which this many live in LDS, the rest in the lane's global memory
+#define RT_HOT_LIMIT (24u * 1024u)   // largest set of small scene tables that is copied into LDS
 #define RT_MAX_SHADOW_JOBS 32  // deferred shadow tests a lane may hold between two trips
 #define RT_CSG_MAX_HITS 16     // hits per composite-shape list
 #define RT_CSG_ARENA 96        // hits across all live lists of one composite query
@@ -205,6 +206,11 @@ struct DScene {
     DAffine background_w2l;
     const uint8_t* lds_blob;     // LBvhNode / LMeshTri arrays of every mesh, staged into LDS by each workgroup
     uint32_t lds_blob_bytes;     // 0: the meshes do not fit; walk the global-memory BVH instead
+    // The small tables (instances, primitives, shaders, lights, ... everything but BVHs, mesh attributes
+    // and texels) lie back to back in one allocation; when that is small enough the kernels copy it
+    // into LDS and follow their pointers there (see localise_scene).
+    const uint8_t* hot_blob;
+    uint32_t hot_bytes;          // 0: too large for LDS, the tables are read from global memory
     uint32_t features;           // RTF_* bits this scene needs
     uint32_t max_ray_spawn;      // most secondary rays one hit can push
     uint32_t max_shadow_spawn;   // most deferred shadow tests one hit can push

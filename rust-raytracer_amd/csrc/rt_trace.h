@@ -26,6 +26,26 @@ RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic + (size_t)RT_LDS_FIX
 
 #define RT_SHADOW_ENTRY 0xFFFFFFFFu
 
+// Copies the scene's small tables into LDS (all threads of the workgroup take part) and returns
+// a scene description whose pointers to those tables lead into the copy.  The device code reads
+// them many times per ray, each read depending on the one before (instance -> primitive ->
+// shader -> child shader ...): out of LDS such a chain costs a fraction of what it costs out of L2.
+RT_DEV DScene localise_scene(const DScene& sc, uint8_t* lds) {
+    DScene l = sc;
+    if (sc.hot_bytes == 0) return l;
+    const uint4* src = reinterpret_cast<const uint4*>(sc.hot_blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < sc.hot_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+#define RT_REBASE(field) if (sc.field) l.field = reinterpret_cast<decltype(l.field)>(lds + (reinterpret_cast<const uint8_t*>(sc.field) - sc.hot_blob))
+    RT_REBASE(instances); RT_REBASE(mesh_instances); RT_REBASE(prims); RT_REBASE(tris); RT_REBASE(polys); RT_REBASE(points);
+    RT_REBASE(faced); RT_REBASE(meshes); RT_REBASE(csg_roots); RT_REBASE(csg_ops); RT_REBASE(csg_leaves);
+    RT_REBASE(shaders); RT_REBASE(shader_bounds); RT_REBASE(shader_child_idx); RT_REBASE(shader_child_weight);
+    RT_REBASE(chain_nmaps); RT_REBASE(normal_maps); RT_REBASE(images); RT_REBASE(gamma_lut); RT_REBASE(lights);
+#undef RT_REBASE
+    return l;
+}
+
 struct LRay {            // a ray in some local space, direction normalised (ray.rs:90-97)
     d3 o, d;
 };

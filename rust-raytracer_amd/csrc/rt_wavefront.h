@@ -171,7 +171,8 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 // ------------------------------------------------------------------ analytic phase
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
-k_wf_analytic(DScene sc, DRenderParams rp, WfArgs a) {
+k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
+    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
@@ -451,7 +452,8 @@ RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32
 // cost the next generation one skipped thread each.
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
-k_wf_shade(DScene sc, DRenderParams rp, WfArgs a) {
+k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
+    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
