@@ -472,6 +472,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
         wa.dropped = (unsigned int*)s->wf_scalars.p + WF_DROPPED;
         wa.rows = (const uint32_t*)s->rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
+        { const char* dbg = std::getenv("RT_WF_DEBUG"); wa.debug = dbg ? (uint32_t)std::atoi(dbg) : 0u; }
     }
     auto run_wavefront = [&](uint32_t mode, double* dst) -> int {
         unsigned int* ws = (unsigned int*)s->wf_scalars.p + mode * WF_PASS_WORDS;

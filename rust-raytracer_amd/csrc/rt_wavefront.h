@@ -78,6 +78,7 @@ struct WfArgs {
     const uint32_t* list;
     const unsigned int* aa_count;
     uint32_t mode;
+    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading
 };
 
 // The shader tree's rays go straight into the next generation's queues, at positions reserved beforehand.
@@ -500,13 +501,15 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
         h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
         h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
         WorldHit wh;
-        world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
+        wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
+        if (!(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
         const DInstance& in = sc.instances[inst];
         if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
         sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
         sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
         sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0;
-        d3 local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
+        d3 local = wh.p;
+        if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
         a.contrib.U(2 * cap, CQ_SLOT, q) = rslot;
         a.contrib.st3(2 * cap, CQ_C, q, rw * local);
         for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
