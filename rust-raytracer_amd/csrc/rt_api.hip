@@ -225,7 +225,13 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 // ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
-    const uint32_t lds = ds.hot_bytes;   // the scene's small tables
+    uint32_t lds = ds.hot_bytes;   // the scene's small tables
+    if (which == 1) { const char* e = std::getenv("RT_SHADE_LDS_PAD"); if (e) lds = std::max(lds, (uint32_t)std::atoi(e)); }   // occupancy experiments
+    if (lds > 48u * 1024u) {
+        const void* fn = which == 0 ? (count ? (const void*)k_wf_analytic<F, true> : (const void*)k_wf_analytic<F, false>)
+                                    : (count ? (const void*)k_wf_shade<F, true> : (const void*)k_wf_shade<F, false>);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (which == 0) {
         if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
         else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
