@@ -149,11 +149,13 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     for (auto& f : hot_fix) *f.first = d.hot_blob + f.second;
     d.hot_bytes = hot.size() <= RT_HOT_LIMIT ? (uint32_t)hot.size() : 0u;
 #define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
+    UP(tlas_nodes, fs.tlas_nodes); UP(tlas_index, fs.tlas_index); UP(tlas_unbounded, fs.tlas_unbounded);
     UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(texels, fs.texels);
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
     d.num_instances = (uint32_t)fs.instances.size();
     d.num_mesh_instances = (uint32_t)fs.mesh_instances.size();
+    d.num_unbounded = (uint32_t)fs.tlas_unbounded.size();
     d.num_lights = (uint32_t)fs.lights.size();
     std::memcpy(d.ambient, fs.ambient, sizeof d.ambient);
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
@@ -208,7 +210,7 @@ int launch_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& 
 }
 constexpr uint32_t V_MESH = RTF_MESH;                                         // rooms + meshes, point lights (glass_monkey)
 constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
-constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES;                           // one-way spheres, skybox, maps (many_balls)
+constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES | RTF_TLAS;                // one-way spheres, skybox, maps, many instances (many_balls)
 constexpr uint32_t V_CSG = RTF_CSG | RTF_FACED | RTF_IMAGES;                  // composite shapes under a skybox
 int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
     auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
@@ -218,7 +220,7 @@ int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t strea
     if (covers(V_BALLS)) return launch_variant<V_BALLS>(count, grid, stream, ds, rp, ta);
     if (covers(V_AREA)) return launch_variant<V_AREA>(count, grid, stream, ds, rp, ta);
     if (covers(V_CSG)) return launch_variant<V_CSG>(count, grid, stream, ds, rp, ta);
-    return launch_variant<RTF_ALL>(count, grid, stream, ds, rp, ta);
+    return launch_variant<RTF_ALL | RTF_TLAS>(count, grid, stream, ds, rp, ta);
 }
 
 constexpr uint32_t RT_MAX_ROUNDS = 40;
@@ -243,7 +245,7 @@ int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, 
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
-constexpr uint32_t V_NO_INLINE = RTF_ALL & ~RTF_INLINE_LIGHTS;
+constexpr uint32_t V_NO_INLINE = (RTF_ALL | RTF_TLAS) & ~RTF_INLINE_LIGHTS;
 int wf_launch(int which, uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
     auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
     if (covers(0u)) return wf_launch_variant<0u>(which, count, grid, stream, ds, rp, wa);

@@ -35,7 +35,10 @@
 #define RTF_WRAP 16u           // OneWay / Inverted
 #define RTF_INLINE_LIGHTS 32u  // lights whose shadow tests cannot be deferred (square, directional, Phong under a ray-spawning Mix)
 #define RTF_IMAGES 64u         // textures, normal / bump maps, skybox
-#define RTF_ALL 127u
+#define RTF_ALL 127u           // (feature bits a scene can have apart from the two below)
+#define RTF_TLAS 256u           // a BVH over the instances (scenes with many of them)
+#define RT_TLAS_STACK 32
+#define RT_TLAS_MIN_INSTANCES 12
 #define RTF_LDS_BVH 128u        // kernel variant: mesh BVHs are walked out of LDS (512-thread workgroups, one per CU)
 
 struct DAffine {               // y = R x + t, rows of R in r[0..3), r[4..7), r[8..11) with t at r[3], r[7], r[11]
@@ -178,6 +181,10 @@ struct alignas(16) TraceJob {  // one scene query of the current trip, between i
 struct DScene {
     const DInstance* instances;  uint32_t num_instances;
     const uint32_t* mesh_instances; uint32_t num_mesh_instances;   // instances whose primitive is an un-wrapped mesh, ascending
+    const DBvhNode* tlas_nodes;      // BVH over the world-space boxes of the bounded instances (null: test every instance in turn)
+    const uint32_t* tlas_index;      // leaf contents: instance indices
+    const uint32_t* tlas_unbounded;  // instances without a finite box (planes, polyhedra, composites): always tested
+    uint32_t num_unbounded;
     const DPrim* prims;
     const DTri* tris;
     const DPoly* polys;

@@ -111,6 +111,8 @@ inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 struct FlatScene {
     std::vector<DInstance> instances;
     std::vector<uint32_t> mesh_instances;
+    std::vector<DBvhNode> tlas_nodes;
+    std::vector<uint32_t> tlas_index, tlas_unbounded;
     std::vector<DPrim> prims;
     std::vector<DTri> tris;
     std::vector<DPoly> polys;
@@ -440,6 +442,8 @@ private:
             const DPrim& p = fs_.prims[fs_.instances[i].prim];
             if (p.kind == DP_MESH && !p.wrap) fs_.mesh_instances.push_back(i);
         }
+        build_tlas();
+        if (!fs_.tlas_nodes.empty()) f |= RTF_TLAS;
         fs_.shader_bounds.assign(d_.num_shaders, 0u);
         for (uint32_t i = 0; i < d_.num_shaders; ++i) {
             uint32_t r = std::min<uint32_t>(count_spawns(i), RT_SHADE_MAX_SPAWN);
@@ -447,6 +451,79 @@ private:
             fs_.shader_bounds[i] = r | (sh << 16);
         }
         fs_.features = f; fs_.max_ray_spawn = max_r; fs_.max_shadow_spawn = max_s; fs_.inline_point_lights = inline_points ? 1 : 0;
+    }
+
+    // Local-space box of a primitive; false when it has none (infinite or not worth bounding).
+    bool prim_bounds(const DPrim& p, V3& lo, V3& hi) const {
+        switch (p.kind) {
+            case DP_SPHERE: { double r = std::fabs(p.p[0]); lo = {-r, -r, -r}; hi = {r, r, r}; return true; }
+            case DP_RECTANGLE: { double w = std::fabs(p.p[0]) / 2, h = std::fabs(p.p[1]) / 2; lo = {-w, -h, 0.0}; hi = {w, h, 0.0}; return true; }
+            case DP_TRIANGLE: {
+                const DTri& t = fs_.tris[p.ref];
+                lo = hi = V3{t.v[0], t.v[1], t.v[2]};
+                for (int k = 1; k < 3; ++k) {
+                    lo = {std::min(lo.x, t.v[3 * k]), std::min(lo.y, t.v[3 * k + 1]), std::min(lo.z, t.v[3 * k + 2])};
+                    hi = {std::max(hi.x, t.v[3 * k]), std::max(hi.y, t.v[3 * k + 1]), std::max(hi.z, t.v[3 * k + 2])};
+                }
+                return true;
+            }
+            case DP_FACED: {   // cube: +-length/2; tetrahedron: every vertex lies within `size` of the centre
+                const DFaced& f = fs_.faced[p.ref];
+                double r = f.is_cube ? std::fabs(f.base_w) / 2 : 0.0;
+                if (!f.is_cube) { const DTri& t = fs_.tris[f.base_tri]; r = std::fabs(t.v[3] - t.v[0]) * 1.01; }
+                lo = {-r, -r, -r}; hi = {r, r, r};
+                return true;
+            }
+            case DP_MESH: { const DMesh& m = fs_.meshes[p.ref]; lo = {m.lo[0], m.lo[1], m.lo[2]}; hi = {m.hi[0], m.hi[1], m.hi[2]}; return true; }
+            default: return false;   // Plane, Polygon, Polyhedron, composite shapes
+        }
+    }
+    void build_tlas() {
+        if (fs_.instances.size() < RT_TLAS_MIN_INSTANCES) return;
+        std::vector<BuildTri> bt;
+        for (uint32_t i = 0; i < fs_.instances.size(); ++i) {
+            const DInstance& in = fs_.instances[i];
+            V3 lo, hi;
+            if (!prim_bounds(fs_.prims[in.prim], lo, hi)) { fs_.tlas_unbounded.push_back(i); continue; }
+            const double inf = std::numeric_limits<double>::infinity();
+            V3 wlo{inf, inf, inf}, whi{-inf, -inf, -inf};
+            const double* m = in.x.l2w.r;
+            for (int c = 0; c < 8; ++c) {
+                V3 q{c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z};
+                V3 w{m[0] * q.x + m[1] * q.y + m[2] * q.z + m[3], m[4] * q.x + m[5] * q.y + m[6] * q.z + m[7], m[8] * q.x + m[9] * q.y + m[10] * q.z + m[11]};
+                wlo = {std::min(wlo.x, w.x), std::min(wlo.y, w.y), std::min(wlo.z, w.z)};
+                whi = {std::max(whi.x, w.x), std::max(whi.y, w.y), std::max(whi.z, w.z)};
+            }
+            // generous padding: the hit distance is measured in instance space and scaled back, not in world space
+            V3 ext = whi - wlo;
+            double pad = 1e-6 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-9 * (std::fabs(wlo.x) + std::fabs(wlo.y) + std::fabs(wlo.z) + std::fabs(whi.x) + std::fabs(whi.y) + std::fabs(whi.z)) + 1e-12;
+            BuildTri b;
+            b.lo = wlo - V3{pad, pad, pad}; b.hi = whi + V3{pad, pad, pad}; b.c = (b.lo + b.hi) * 0.5; b.face = i;
+            bt.push_back(b);
+        }
+        if (bt.size() < RT_TLAS_MIN_INSTANCES) { fs_.tlas_unbounded.clear(); return; }
+        std::vector<BuildNode> bn(1);
+        bn.reserve(2 * bt.size() + 2);
+        build_bvh(bt, bn, 0, 0, (uint32_t)bt.size(), 0);
+        for (const BuildTri& b : bt) fs_.tlas_index.push_back(b.face);
+        std::vector<int> interior_index(bn.size(), -1);
+        std::vector<int> order;
+        for (size_t i = 0; i < bn.size(); ++i) if (bn[i].left >= 0) { interior_index[i] = (int)order.size(); order.push_back((int)i); }
+        auto child_ref = [&](int b) -> uint32_t {
+            if (bn[b].left >= 0) return (uint32_t)interior_index[b];
+            return 0x80000000u | (bn[b].count << 28) | bn[b].first;
+        };
+        auto set_box = [&](DBvhNode& n, int k, const BuildNode& b) {
+            n.lo[k][0] = b.lo.x; n.lo[k][1] = b.lo.y; n.lo[k][2] = b.lo.z;
+            n.hi[k][0] = b.hi.x; n.hi[k][1] = b.hi.y; n.hi[k][2] = b.hi.z;
+        };
+        for (int b : order) {
+            DBvhNode n{};
+            set_box(n, 0, bn[bn[b].left]); set_box(n, 1, bn[bn[b].right]);
+            n.child[0] = child_ref(bn[b].left); n.child[1] = child_ref(bn[b].right);
+            fs_.tlas_nodes.push_back(n);
+        }
+        if (fs_.tlas_nodes.empty()) { fs_.tlas_index.clear(); fs_.tlas_unbounded.clear(); }   // a single leaf: not worth it
     }
 
     void walk(uint32_t i, const Mat4& parent_l2w, const Mat4& parent_w2l) {

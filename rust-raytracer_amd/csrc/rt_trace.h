@@ -815,15 +815,19 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
 //   any == true:  SceneNode::partial_trace_until_distance (src/scene.rs:227-248) — does anything
 //                 lie closer than max_distance ('<=' for the root's own primitive, '<' below it)?
 // With SKIP_MESH the un-wrapped mesh instances are left out: the caller walks them for a
-// whole batch of rays at once (mesh_walk_batch) and merges the results.
+// whole batch of rays at once (mesh_walk_batch / k_wf_walk) and merges the results.
+// Scenes with many instances carry a BVH over the instances' world-space boxes (RTF_TLAS); the
+// reference tests every child of a node in turn (src/scene.rs:205-217), which only fixes the
+// winner among equal distances: the earlier instance, kept here by an explicit tie rule.
 template <uint32_t F, bool COUNT, bool SKIP_MESH>
 RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk) {
     bool found = false;
     double best = any ? max_distance : INFINITY;
-    for (uint32_t i = 0; i < sc.num_instances; ++i) {
+    // one instance; returns true when an any-hit query is settled
+    auto visit = [&](uint32_t i) -> bool {
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
-        if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) continue; }
+        if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) return false; }
         double s, inv_s;
         LRay lr = to_local(in.x, o, d, s, inv_s);
         RT_COUNT(wk, instance_tests);
@@ -836,19 +840,50 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
                 // one call site for both query kinds: shadow lanes and camera/secondary lanes walk together
                 c.b = 0;
                 got = mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], lr, any, best * s, in.is_root != 0, c.t, c.a, wk);
-                if (any) { if (got) return true; continue; }
+                if (any) return got;
             }
         } else {
             got = prim_closest<F, COUNT>(sc, p, lr, any ? INFINITY : best * s, c, wk);
-            if (any) {
-                if (got && (in.is_root ? c.t <= max_distance * s : c.t < max_distance * s)) return true;
-                continue;
+            if (any) return got && (in.is_root ? c.t <= max_distance * s : c.t < max_distance * s);
+        }
+        if (!got) return false;
+        double tw = c.t * inv_s;
+        if (tw < best || (tw == best && found && i < hit.inst)) { best = tw; hit.inst = i; hit.c = c; found = true; }
+        return false;
+    };
+    bool walked = false;
+    if constexpr (F & RTF_TLAS) {
+        if (sc.tlas_nodes) {
+            walked = true;
+            for (uint32_t k = 0; k < sc.num_unbounded; ++k) if (visit(sc.tlas_unbounded[k])) return true;
+            const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            uint32_t stack[RT_TLAS_STACK];
+            int sp = 0;
+            uint32_t cur = 0;
+            while (cur != RT_WALK_DONE) {
+                if (cur & 0x80000000u) {                           // leaf: a few instances
+                    uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+                    for (uint32_t k = 0; k < cnt; ++k) if (visit(sc.tlas_index[base + k])) return true;
+                    cur = sp > 0 ? stack[--sp] : RT_WALK_DONE;
+                    continue;
+                }
+                const DBvhNode& n = sc.tlas_nodes[cur];
+                double tn0, tn1;
+                RT_COUNT(wk, box_tests); RT_COUNT(wk, box_tests);
+                bool h0 = slab(n.lo[0], n.hi[0], o, inv, best, tn0);
+                bool h1 = slab(n.lo[1], n.hi[1], o, inv, best, tn1);
+                if (h0 && h1) {
+                    bool swap = tn1 < tn0;
+                    cur = swap ? n.child[1] : n.child[0];
+                    if (sp < RT_TLAS_STACK) stack[sp++] = swap ? n.child[0] : n.child[1];
+                } else if (h0) cur = n.child[0];
+                else if (h1) cur = n.child[1];
+                else cur = sp > 0 ? stack[--sp] : RT_WALK_DONE;
             }
         }
-        if (!got) continue;
-        double tw = c.t * inv_s;
-        if (tw < best) { best = tw; hit.inst = i; hit.c = c; found = true; }
     }
+    if (!walked)
+        for (uint32_t i = 0; i < sc.num_instances; ++i) if (visit(i)) return true;
     hit.t = best;
     return found;
 }
