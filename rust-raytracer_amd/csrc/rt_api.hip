@@ -385,7 +385,8 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     // hand-over queues between rounds, one accumulator per sample slot
     const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 22), 1u << 25);
     const size_t acc_slots = npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u);
-    for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
+    const bool wavefront = use_wavefront(s->ds.features);
+    if (!wavefront) for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
     {
         bool fresh = s->acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
         if ((e = s->acc.ensure(acc_slots * RT_ACC_LIMBS * 8)) != RT_OK) return e;
@@ -405,7 +406,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     // persistent grid: enough waves to fill every CU several times over; each pulls tiles until none are left
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
     const uint32_t max_waves = (uint32_t)s->num_cus * 8;           // two waves per SIMD: all the register file allows
-    if ((e = s->lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
+    if (!wavefront && (e = s->lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
     // Queries per trip.  Depth-first order (one ray per trip) needs at most per_level x depth + spawn + 1
@@ -456,7 +457,6 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         return RT_OK;
     };
     // ---- the other schedule: ray queues in HBM, one generation of rays per set of launches
-    const bool wavefront = use_wavefront(s->ds.features);
     const uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
     WfArgs wa{};
     if (wavefront) {

@@ -31,10 +31,14 @@ def small_view(scene, width, **kw):
 
 @pytest.fixture(scope="module")
 def device_scene(render_mod, scene_cache):
-    cache = {}
+    cache = {}   # the most recently used few: every device scene owns gigabytes of ray queues
 
     def get(name):
-        if name not in cache:
+        if name in cache:
+            cache[name] = cache.pop(name)
+        else:
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache))).close()
             cache[name] = render_mod.DeviceScene(scene_cache(name), device=0)
         return cache[name]
     yield get
