@@ -62,7 +62,6 @@ struct RtScene {
     int num_cus = 256;
     DScene ds{};
     std::vector<void*> owned;
-    uint32_t max_spawn = 0;
     uint32_t lds_limit = 65536;
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
@@ -290,7 +289,7 @@ bool use_wavefront(uint32_t features) {
 }
 
 // Layout of the per-frame scalar block (u32 words), zeroed at the start of every frame.
-constexpr uint32_t SC_AA_COUNT = 0, SC_ACC_ALLOC0 = 1, SC_ACC_ALLOC1 = 2;
+constexpr uint32_t SC_AA_COUNT = 0;
 constexpr uint32_t SC_NEXT0 = 16, SC_NEXT1 = SC_NEXT0 + RT_MAX_ROUNDS + 1;          // work counters, one per round
 constexpr uint32_t SC_QUEUE0 = SC_NEXT1 + RT_MAX_ROUNDS + 1, SC_QUEUE1 = SC_QUEUE0 + RT_MAX_ROUNDS + 1;   // queue fill, one per round
 constexpr uint32_t SC_IDLE0 = SC_QUEUE1 + RT_MAX_ROUNDS + 1, SC_IDLE1 = SC_IDLE0 + RT_MAX_ROUNDS + 1;      // idle lanes, one per round

@@ -141,9 +141,8 @@ RT_DEV void phong_lit(PhongCtx& c, double surface_dot, d3 light_direction, d3 in
     c.total = c.total + phong_color * surface_dot * intensity;
 }
 
-// SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
-// an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
-// order so that the draw counter of the RNG advances identically.
+// Shadow test of Lightable::get_illums_at (src/light.rs:31-36): does anything lie between the
+// hit point and the light?  Used by the lights that are evaluated inside the shader.
 template <uint32_t F, bool COUNT>
 RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COUNT>& wk) {
     SceneHit h;
@@ -151,6 +150,9 @@ RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COU
     return trace_scene<F, COUNT, false>(sc, o, d, true, max_distance, h, wk);
 }
 
+// SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
+// an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
+// order so that the draw counter of the RNG advances identically.
 template <uint32_t F, bool COUNT>
 RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
     struct Quad { double minx, miny, maxx, maxy; uint32_t depth; };

@@ -249,22 +249,6 @@ RT_DEV bool polyhedron_hit(const DScene& sc, const DPrim& ph, const LRay& r, dou
 }
 
 // ------------------------------------------------------------------ mesh (src/mesh.rs)
-// Mesh::check_triangle :416-447 without the attribute interpolation: distance only.
-RT_DEV bool mesh_tri_hit(const DMeshTri& tr, const LRay& r, double& t) {
-    d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3), normal = ld3(tr.n);
-    double origin_dot = dot(normal, r.o - v1);
-    double direction_dot = dot(normal, r.d);
-    double hit_distance = -origin_dot / direction_dot;
-    if (hit_distance > RT_MIN_DISTANCE) {
-        d3 p = r.o + (hit_distance * r.d);
-        if (dot(cross(v2 - v1, p - v1), normal) < 0.0) return false;
-        if (dot(cross(v3 - v2, p - v2), normal) < 0.0) return false;
-        if (dot(cross(v1 - v3, p - v3), normal) < 0.0) return false;
-        t = hit_distance;
-        return true;
-    }
-    return false;
-}
 RT_DEV void mesh_details(const DScene& sc, const DMesh& m, const DMeshTri& tr, const LRay& r, double t, Details& o) {   // :429-462
     d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3);
     o.p = r.o + (t * r.d);
