@@ -69,7 +69,11 @@ struct RtScene {
     DeviceBuf queue[2], acc, acc_flags, lane_mem;
     // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
     DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;
-    uint32_t wf_cap = 0;   // hand-over queues between rounds, split-sample accumulators
+    uint32_t wf_cap = 0;
+    // A generation that does not fit the queues loses rays; the frame is then redone by the persistent
+    // kernel (which hands rays on between rounds and cannot overflow) and the scene stays on it.
+    unsigned int* h_dropped = nullptr;     // pinned: rays dropped by the last queue-pipeline frame
+    bool last_used_queues = false, queue_overflowed = false;   // hand-over queues between rounds, split-sample accumulators
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -101,6 +105,7 @@ void rt_scene_destroy(RtScene* s) {
                          &s->wf_rays[0], &s->wf_rays[1], &s->wf_shadows[0], &s->wf_shadows[1], &s->wf_rjobs, &s->wf_sjobs, &s->wf_contrib,
                          &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->h_dropped) (void)hipHostFree(s->h_dropped);
     delete s;
 }
 
@@ -174,6 +179,8 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     }
     for (auto& e : s->ev)
         if (hipEventCreate(&e) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    if (hipHostMalloc((void**)&s->h_dropped, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipHostMalloc failed"); }
+    *s->h_dropped = 0;
     *out = s;
     return RT_OK;
 }
@@ -384,7 +391,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     // hand-over queues between rounds, one accumulator per sample slot
     const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 22), 1u << 25);
     const size_t acc_slots = npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u);
-    const bool wavefront = use_wavefront(s->ds.features);
+    const bool wavefront = use_wavefront(s->ds.features) && !s->queue_overflowed;
     if (!wavefront) for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
     {
         bool fresh = s->acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
@@ -456,7 +463,8 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         return RT_OK;
     };
     // ---- the other schedule: ray queues in HBM, one generation of rays per set of launches
-    const uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
+    uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
+    if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, 1L << 26); }   // tests: provoke an overflow
     WfArgs wa{};
     if (wavefront) {
         const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
@@ -543,6 +551,8 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev[3], stream));
+    s->last_used_queues = wavefront;
+    if (wavefront) HIP_TRY(hipMemcpyAsync(s->h_dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     s->timed = true;
     s->acc_dirty = false;
     return RT_OK;
@@ -574,8 +584,18 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     bool count = d_aux && d_aux->count_work;
+    // an earlier asynchronous frame that lost rays (known once it has finished) moves the scene to the persistent kernel
+    if (s->last_used_queues && *s->h_dropped > 0) s->queue_overflowed = true;
     rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, count, stream);
     if (rc != RT_OK) return rc;
+    if (count && s->last_used_queues) {   // this variant of the call synchronises anyway: redo a frame that lost rays at once
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (*s->h_dropped > 0) {
+            s->queue_overflowed = true;
+            rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, count, stream);
+            if (rc != RT_OK) return rc;
+        }
+    }
     if (d_aux) {
         const size_t npix = (size_t)dim->width * dim->height;
         if (d_aux->color) HIP_TRY(hipMemcpyAsync(d_aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -589,11 +609,7 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
             HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
-            if (s->wf_scalars.p && use_wavefront(s->ds.features)) {
-                unsigned int dropped = 0;
-                HIP_TRY(hipMemcpy(&dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof dropped, hipMemcpyDeviceToHost));
-                c.stack_overflows += dropped;
-            }
+            if (s->last_used_queues) c.stack_overflows += *s->h_dropped;
             fill_counters(d_aux->counters, c);
         }
     }
@@ -635,6 +651,13 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
         bool count = aux && aux->count_work;
         rc = enqueue_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
         if (rc != RT_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (s->last_used_queues && *s->h_dropped > 0) {   // a generation outgrew the queues: redo the frame with the persistent kernel
+            s->queue_overflowed = true;
+            HIP_TRY(hipMemsetAsync(s->rgb_full.p, 0, rgb_bytes, nullptr));
+            rc = enqueue_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
+            if (rc != RT_OK) return rc;
+        }
         HIP_TRY(hipMemcpy(rgb_out, s->rgb_full.p, rgb_bytes, hipMemcpyDeviceToHost));
         if (aux) {
             if (aux->color) HIP_TRY(hipMemcpy(aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -646,11 +669,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
-            if (s->wf_scalars.p && use_wavefront(s->ds.features)) {
-                unsigned int dropped = 0;
-                HIP_TRY(hipMemcpy(&dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof dropped, hipMemcpyDeviceToHost));
-                c.stack_overflows += dropped;
-            }
+            if (s->last_used_queues) c.stack_overflows += *s->h_dropped;
             fill_counters(aux->counters, c);
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
@@ -663,7 +682,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
                          100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
         }
-        if (std::getenv("RT_DEBUG_ROUNDS") && s->wf_scalars.p && use_wavefront(s->ds.features)) {   // queue fill per generation
+        if (std::getenv("RT_DEBUG_ROUNDS") && s->wf_scalars.p && s->last_used_queues) {   // queue fill per generation
             std::vector<unsigned int> ws(WF_SCALAR_BYTES / 4);
             HIP_TRY(hipMemcpy(ws.data(), s->wf_scalars.p, WF_SCALAR_BYTES, hipMemcpyDeviceToHost));
             for (int pass = 0; pass < 2; ++pass) {

@@ -225,3 +225,22 @@ def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatc
     for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_aa", "shade_evals", "tri_tests", "stack_overflows"):
         assert a["counters"][k] == b["counters"][k], (name, k)
     assert a["counters"]["stack_overflows"] == 0
+
+
+def test_queue_overflow_falls_back_to_the_persistent_kernel(render_mod, scene_cache, monkeypatch):
+    s = scene_cache("glass_monkey")
+    dim, cam, cfg = small_view(s, 200, anti_alias=True, seed=1)
+    ref = render_mod.DeviceScene(s, device=0)
+    want = ref.render(dim, cam, cfg, count_work=True)
+    ref.close()
+    # queues far too small for this frame: the library must notice the lost rays and redo the frame
+    monkeypatch.setenv("RT_WF_CAP", "32768")
+    ds = render_mod.DeviceScene(s, device=0)
+    got = ds.render(dim, cam, cfg, count_work=True)
+    again = ds.render(dim, cam, cfg)          # the scene now stays on the persistent kernel
+    ds.close()
+    monkeypatch.delenv("RT_WF_CAP", raising=False)
+    for r in (got, again):
+        assert np.array_equal(r["color"], want["color"]) and np.array_equal(r["hit_id"], want["hit_id"])
+    assert got["counters"]["stack_overflows"] == 0
+    assert got["counters"]["rays_total"] == want["counters"]["rays_total"]
