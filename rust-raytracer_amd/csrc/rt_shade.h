@@ -153,66 +153,146 @@ RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COU
 // SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
 // an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
 // order so that the draw counter of the RNG advances identically.
+//
+// A quadrant whose four probes are all lit is filled with 4^depth unshadowed samples
+// (guess_illums, :222-245), up to 1024 Phong terms for one hit: by far the largest piece of work
+// of an area-lit scene, and one lane's alone.  Here the lanes that entered this function
+// together stay in its loop until all of them are done, and every such batch of samples is
+// spread over all of them: the random draws are counter-based, so sample i can be evaluated by
+// any lane, and the terms are summed in fixed point (integer limbs, like the frame's
+// accumulators), so the sum does not depend on which lanes helped.  It differs from the
+// reference's left-to-right f64 sum by rounding only (relative 1e-16 per term).
+RT_DEV d3 phong_term(d3 n, d3 view, d3 diffuse, d3 specular, double shininess, double surface_dot, d3 light_direction, d3 intensity) {
+    d3 reflection_direction = normalize(2.0 * surface_dot * n - light_direction);
+    double specular_factor = pow(fmax(dot(reflection_direction, view), 0.0), shininess) / surface_dot;
+    d3 phong_color = specular * specular_factor + diffuse;
+    return phong_color * surface_dot * intensity;
+}
+RT_DEV d3 bcast3(d3 v, int src) { return mk3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)); }
 template <uint32_t F, bool COUNT>
 RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
+    __shared__ unsigned long long guess_acc[16][9];               // per wave: 3 channels x 3 limbs of weight 2^0, 2^-40, 2^-80
     struct Quad { double minx, miny, maxx, maxy; uint32_t depth; };
     Quad st[16];
     int sp = 0;
     double half = L.size * 0.5;
     st[sp++] = Quad{-half, -half, half, half, 5u};                // SUB_DEPTH = 5, light.rs:187
     uint32_t counter = 0;
-    d3 lpos = ld3(L.position), lcol = ld3(L.color);
-    while (sp > 0) {
-        Quad q = st[--sp];
-        // subdivide_points :206-218 — four jittered samples, eight draws
-        double chx = q.maxx - q.minx, chy = q.maxy - q.miny;
-        double lowx = q.minx + chx * 0.25, lowy = q.miny + chy * 0.25;
-        double highx = q.minx + chx * 0.75, highy = q.miny + chy * 0.75;
-        double cx[4] = {lowx, highx, lowx, lowx + chx * 0.5};
-        double cz[4] = {lowy + chy * 0.5, highy, lowy, lowy};
-        double rx = chx * 0.25, ry = chy * 0.25;
-        double area_porp = (q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25;   // :251
-        double s_dot[4]; d3 s_dir[4]; d3 s_int[4]; bool s_lit[4];
-        uint32_t lit_count = 0;
-        for (int s = 0; s < 4; ++s) {
-            double dx = -rx + (rx - (-rx)) * rng_light(stream, path, L.index, counter++);
-            double dz = -ry + (ry - (-ry)) * rng_light(stream, path, L.index, counter++);
-            d3 light_pos = lpos + mk3(cx[s] + dx, 0.0, cz[s] + dz);
-            d3 hit_to_light = light_pos - c.p;
-            d3 light_direction = normalize(hit_to_light);
-            double surface_dot = dot(light_direction, c.n);
-            s_lit[s] = false;
-            if (surface_dot <= 0.0) continue;
-            double light_distance = length(hit_to_light);
-            if (occluded<F, COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
-            s_lit[s] = true; s_dot[s] = surface_dot; s_dir[s] = light_direction;
-            s_int[s] = lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
-            lit_count++;
+    const d3 lpos = ld3(L.position), lcol = ld3(L.color);
+    const uint32_t lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) & 15u;
+    for (;;) {
+        const bool busy = sp > 0;
+        if (__ballot(busy) == 0ull) break;                         // idle lanes stay on as helpers
+        bool task = false;                                         // a batch of unshadowed samples to evaluate
+        double tminx = 0.0, tminy = 0.0, tmaxx = 0.0, tmaxy = 0.0, tap = 0.0;
+        uint32_t tn = 0, tcounter = 0;
+        if (busy) {
+            Quad q = st[--sp];
+            // subdivide_points :206-218 — four jittered samples, eight draws
+            double chx = q.maxx - q.minx, chy = q.maxy - q.miny;
+            double lowx = q.minx + chx * 0.25, lowy = q.miny + chy * 0.25;
+            double highx = q.minx + chx * 0.75, highy = q.miny + chy * 0.75;
+            double cx[4] = {lowx, highx, lowx, lowx + chx * 0.5};
+            double cz[4] = {lowy + chy * 0.5, highy, lowy, lowy};
+            double rx = chx * 0.25, ry = chy * 0.25;
+            double area_porp = (q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25;   // :251
+            double s_dot[4]; d3 s_dir[4]; d3 s_int[4]; bool s_lit[4];
+            uint32_t lit_count = 0;
+            for (int s = 0; s < 4; ++s) {
+                double dx = -rx + (rx - (-rx)) * rng_light(stream, path, L.index, counter++);
+                double dz = -ry + (ry - (-ry)) * rng_light(stream, path, L.index, counter++);
+                d3 light_pos = lpos + mk3(cx[s] + dx, 0.0, cz[s] + dz);
+                d3 hit_to_light = light_pos - c.p;
+                d3 light_direction = normalize(hit_to_light);
+                double surface_dot = dot(light_direction, c.n);
+                s_lit[s] = false;
+                if (surface_dot <= 0.0) continue;
+                double light_distance = length(hit_to_light);
+                if (occluded<F, COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
+                s_lit[s] = true; s_dot[s] = surface_dot; s_dir[s] = light_direction;
+                s_int[s] = lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
+                lit_count++;
+            }
+            if (q.depth == 1 || lit_count == 0) {                 // :277-279
+                for (int s = 0; s < 4; ++s) if (s_lit[s]) { RT_COUNT(wk, shade_evals); phong_lit(c, s_dot[s], s_dir[s], s_int[s]); }
+            } else if (lit_count == 4) {                          // guess_illums :222-245
+                task = true;
+                tminx = q.minx; tminy = q.miny; tmaxx = q.maxx; tmaxy = q.maxy;
+                tn = 1u << (2 * q.depth);
+                tap = 4.0 * area_porp / (double)tn;
+                tcounter = counter;
+                counter += 2u * tn;
+            } else {                                              // :284-297, children pushed in reverse visiting order
+                double hx = (q.maxx - q.minx) * 0.5, hy = (q.maxy - q.miny) * 0.5;
+                double midx = q.minx + hx, midy = q.miny + hy;
+                if (sp + 4 <= 16) {
+                    st[sp++] = Quad{q.minx + hx, q.miny, q.maxx, q.maxy - hy, q.depth - 1};   // (bot, right)
+                    st[sp++] = Quad{q.minx, q.miny, midx, midy, q.depth - 1};                 // (min, mid)
+                    st[sp++] = Quad{midx, midy, q.maxx, q.maxy, q.depth - 1};                 // (mid, max)
+                    st[sp++] = Quad{q.minx, q.miny + hy, q.maxx - hx, q.maxy, q.depth - 1};   // (left, top)
+                }
+            }
         }
-        if (q.depth == 1 || lit_count == 0) {                     // :277-279
-            for (int s = 0; s < 4; ++s) if (s_lit[s]) { RT_COUNT(wk, shade_evals); phong_lit(c, s_dot[s], s_dir[s], s_int[s]); }
-        } else if (lit_count == 4) {                              // guess_illums :222-245
-            uint32_t num_illums = 1u << (2 * q.depth);
-            double ap = 4.0 * area_porp / (double)num_illums;
-            for (uint32_t i = 0; i < num_illums; ++i) {
-                double sx = q.minx + (q.maxx - q.minx) * rng_light(stream, path, L.index, counter++);
-                double sz = q.miny + (q.maxy - q.miny) * rng_light(stream, path, L.index, counter++);
-                d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - c.p;
+        unsigned long long pend = __ballot(task);
+        if (pend == 0ull) continue;
+        const unsigned long long here = __ballot(1);
+        const uint32_t helpers = (uint32_t)__popcll(here), rank = (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
+        while (pend) {
+            const int src = __ffsll((long long)pend) - 1;
+            pend &= pend - 1ull;
+            // the owner's hit and batch
+            const d3 P = bcast3(c.p, src), N = bcast3(c.n, src), V = bcast3(c.view, src);
+            const d3 KD = bcast3(c.diffuse, src), KS = bcast3(c.specular, src);
+            const double SH = __shfl(c.shininess, src);
+            const double bminx = __shfl(tminx, src), bminy = __shfl(tminy, src), bmaxx = __shfl(tmaxx, src), bmaxy = __shfl(tmaxy, src);
+            const double bap = __shfl(tap, src);
+            const uint32_t bn = __shfl(tn, src), bcounter = __shfl(tcounter, src), bpath = __shfl(path, src);
+            const uint64_t bstream = ((uint64_t)__shfl((uint32_t)(stream >> 32), src) << 32) | (uint64_t)__shfl((uint32_t)stream, src);
+            if ((int)lane == src) for (int k = 0; k < 9; ++k) guess_acc[wave][k] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            double l[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            bool odd = false;                                      // a term that fixed point cannot hold (non-finite, huge)
+            for (uint32_t i = rank; i < bn; i += helpers) {
+                double sx = bminx + (bmaxx - bminx) * rng_light(bstream, bpath, L.index, bcounter + 2u * i);
+                double sz = bminy + (bmaxy - bminy) * rng_light(bstream, bpath, L.index, bcounter + 2u * i + 1u);
+                d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - P;
                 double light_distance = length(hit_to_light);
                 d3 light_direction = hit_to_light / light_distance;
-                double surface_dot = dot(light_direction, c.n);
+                double surface_dot = dot(light_direction, N);
                 RT_COUNT(wk, shade_evals);
-                phong_lit(c, surface_dot, light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * ap);
+                d3 term = phong_term(N, V, KD, KS, SH, surface_dot, light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * bap);
+                const double tv[3] = {term.x, term.y, term.z};
+                for (int ch = 0; ch < 3; ++ch) {
+                    const double v = tv[ch];
+                    if (!(fabs(v) < 0x1p40)) { odd = true; continue; }
+                    double l0 = trunc(v);
+                    double r1 = (v - l0) * 0x1p40;
+                    double l1 = trunc(r1);
+                    double l2 = trunc((r1 - l1) * 0x1p40);
+                    l[3 * ch] += l0; l[3 * ch + 1] += l1; l[3 * ch + 2] += l2;
+                }
             }
-        } else {                                                  // :284-297, children pushed in reverse visiting order
-            double hx = (q.maxx - q.minx) * 0.5, hy = (q.maxy - q.miny) * 0.5;
-            double midx = q.minx + hx, midy = q.miny + hy;
-            if (sp + 4 <= 16) {
-                st[sp++] = Quad{q.minx + hx, q.miny, q.maxx, q.maxy - hy, q.depth - 1};   // (bot, right)
-                st[sp++] = Quad{q.minx, q.miny, midx, midy, q.depth - 1};                 // (min, mid)
-                st[sp++] = Quad{midx, midy, q.maxx, q.maxy, q.depth - 1};                 // (mid, max)
-                st[sp++] = Quad{q.minx, q.miny + hy, q.maxx - hx, q.maxy, q.depth - 1};   // (left, top)
+            for (int k = 0; k < 9; ++k) if (l[k] != 0.0) atomicAdd(&guess_acc[wave][k], (unsigned long long)(long long)l[k]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool any_odd = __ballot(odd) != 0ull;
+            if ((int)lane == src) {
+                if (any_odd) {                                    // rare: evaluate this batch the reference's way, term by term
+                    for (uint32_t i = 0; i < tn; ++i) {
+                        double sx = tminx + (tmaxx - tminx) * rng_light(stream, path, L.index, tcounter + 2u * i);
+                        double sz = tminy + (tmaxy - tminy) * rng_light(stream, path, L.index, tcounter + 2u * i + 1u);
+                        d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - c.p;
+                        double light_distance = length(hit_to_light);
+                        d3 light_direction = hit_to_light / light_distance;
+                        phong_lit(c, dot(light_direction, c.n), light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * tap);
+                    }
+                } else {
+                    const unsigned long long* g = guess_acc[wave];
+                    c.total = c.total + mk3(((double)(long long)g[2] * 0x1p-80 + (double)(long long)g[1] * 0x1p-40) + (double)(long long)g[0],
+                                            ((double)(long long)g[5] * 0x1p-80 + (double)(long long)g[4] * 0x1p-40) + (double)(long long)g[3],
+                                            ((double)(long long)g[8] * 0x1p-80 + (double)(long long)g[7] * 0x1p-40) + (double)(long long)g[6]);
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 }
