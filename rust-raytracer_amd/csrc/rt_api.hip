@@ -234,6 +234,7 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
     uint32_t lds = ds.hot_bytes;   // the scene's small tables
+    if (which == 1) lds = ((ds.hot_bytes + 15u) & ~15u) + 4u * 640u * 8u;   // + accumulation staging of the four waves
     if (which == 1) { const char* e = std::getenv("RT_SHADE_LDS_PAD"); if (e) lds = std::max(lds, (uint32_t)std::atoi(e)); }   // occupancy experiments
     if (lds > 48u * 1024u) {
         const void* fn = which == 0 ? (count ? (const void*)k_wf_analytic<F, true> : (const void*)k_wf_analytic<F, false>)
@@ -472,7 +473,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         for (auto& b : s->wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
         if ((e = s->wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if ((e = s->wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
-        if ((e = s->wf_contrib.ensure(2 * n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
+        if (s->ds.has_background && (e = s->wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
         if ((e = s->wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
         if ((e = s->wf_overflow.ensure((size_t)s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;
         if ((e = s->wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
@@ -482,7 +483,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wa.rjobs = queue(s->wf_rjobs, n, JQ_NF); wa.sjobs = queue(s->wf_sjobs, n, JQ_NF);
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
         wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min();
-        wa.contrib = queue(s->wf_contrib, 2 * n, CQ_NF);
+        wa.contrib = queue(s->wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
         wa.dropped = (unsigned int*)s->wf_scalars.p + WF_DROPPED;
@@ -513,8 +514,10 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
             }
             lrc = wf_launch(1, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
             if (lrc != RT_OK) return lrc;
-            hipLaunchKernelGGL(k_wf_accumulate, dim3(grid), dim3(256), 0, stream, wa);
-            HIP_TRY(hipGetLastError());
+            if (s->ds.has_background) {
+                hipLaunchKernelGGL(k_wf_accumulate, dim3(grid), dim3(256), 0, stream, wa);
+                HIP_TRY(hipGetLastError());
+            }
         }
         if (mode == 0)
             hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, wa.acc, wa.acc_flags, (const unsigned int*)nullptr, 0u, (uint32_t)npix, dst);

@@ -45,7 +45,7 @@ enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH
 enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
 // query records (TraceJob): 2 doubles, 5 words
 enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
-// colour terms: 3 doubles, 1 word (slot, RT_NO_SLOT: nothing); rays at [0, cap), shadow tests at [cap, 2 cap)
+// colour terms of the analytic phase (sky-box scenes): 3 doubles, 1 word (slot, RT_NO_SLOT: nothing), one per ray entry
 enum { CQ_C = 0, CQ_NF = 3, CQ_SLOT = 0, CQ_NU = 1 };
 
 struct WfArgs {
@@ -65,7 +65,7 @@ struct WfArgs {
     uint32_t* walk_overflow;          // (RT_BVH_STACK - RT_WF_LDS_STACK) words per walk thread
     uint32_t refill_min;
     // outputs
-    WfQueue contrib;                  // 2*cap entries
+    WfQueue contrib;                  // cap entries
     unsigned long long* acc;
     uint32_t* acc_flags;
     double* distance;
@@ -187,25 +187,27 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         d3 o, d;
         double max_distance = 0.0;
         if (shadow) {
-            a.contrib.U(2 * cap, CQ_SLOT, cap + q) = RT_NO_SLOT;
             if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { jobs.U(cap, JQ_FLAGS, q) = 7u; continue; }        // a hole
             o = a.shadows.ld3(cap, SQ_O, q); d = a.shadows.ld3(cap, SQ_D, q); max_distance = a.shadows.F(cap, SQ_DIST, q);
             RT_COUNT(wk, rays_shadow);
         } else {
             const uint32_t flags = a.rays.U(cap, RQ_FLAGS, q);
-            if (flags & 8u) { a.contrib.U(2 * cap, CQ_SLOT, q) = RT_NO_SLOT; jobs.U(cap, JQ_FLAGS, q) = 6u; continue; }   // a hole
+            if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
+            if (flags & 8u) { jobs.U(cap, JQ_FLAGS, q) = 6u; continue; }   // a hole
             o = a.rays.ld3(cap, RQ_O, q); d = a.rays.ld3(cap, RQ_D, q);
             const d3 rc = a.rays.ld3(cap, RQ_C, q);
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
             if (!(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
                 const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
-                a.contrib.U(2 * cap, CQ_SLOT, q) = slot;
-                a.contrib.st3(2 * cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, d));
+                // its colour term: the background (k_wf_accumulate adds it); exactly nothing without a sky box
+                if (sc.has_background) {
+                    a.contrib.U(cap, CQ_SLOT, q) = slot;
+                    a.contrib.st3(cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, d));
+                }
                 if (flags & 1u) { a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
                 jobs.U(cap, JQ_FLAGS, q) = 6u;
                 continue;
             }
-            a.contrib.U(2 * cap, CQ_SLOT, q) = RT_NO_SLOT;
             if (COUNT) { if (flags & 2u) cam++; else wk.rays_secondary++; }
         }
         SceneHit h;
@@ -447,37 +449,76 @@ RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32
     rbase = (uint32_t)at; sbase = (uint32_t)(at >> 32);
 }
 
+// Adds one colour term per lane (slot RT_NO_SLOT: none) to the accumulators, the whole wave at once:
+// the terms' limbs go through LDS so that nine neighbouring lanes hold the nine limbs of one sample,
+// whose atomics then fall into one or two cache lines (four times the rate of one lane per term).
+// `stage` is the wave's own 64 x 10 words of LDS.  Every lane of the wave must call.
+RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const double v[3] = {c.x, c.y, c.z};
+    for (int ch = 0; ch < 3; ++ch) {
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+        if (slot != RT_NO_SLOT) {
+            if (!(fabs(v[ch]) < 0x1p40)) {
+                uint32_t bit = (v[ch] != v[ch]) ? 4u : (v[ch] > 0.0 ? 1u : 2u);
+                atomicOr(acc_flags + slot, bit << (3 * ch));
+            } else {
+                l0 = trunc(v[ch]);
+                double r1 = (v[ch] - l0) * 0x1p40;
+                l1 = trunc(r1);
+                l2 = trunc((r1 - l1) * 0x1p40);
+            }
+        }
+        stage[lane * 10u + 3 * ch] = (unsigned long long)(long long)l0;
+        stage[lane * 10u + 3 * ch + 1] = (unsigned long long)(long long)l1;
+        stage[lane * 10u + 3 * ch + 2] = (unsigned long long)(long long)l2;
+    }
+    stage[lane * 10u + 9u] = slot;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t t = lane; t < 64u * RT_ACC_LIMBS; t += 64u) {
+        const uint32_t rec = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
+        const uint32_t rslot = (uint32_t)stage[rec * 10u + 9u];
+        const unsigned long long l = stage[rec * 10u + limb];
+        if (rslot != RT_NO_SLOT && l != 0ull) atomicAdd(acc + (size_t)rslot * RT_ACC_LIMBS + limb, l);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // A hit's new rays and shadow tests are written straight into the next generation's queues.  Room
-// for the most its material can ask for is reserved first (one atomic per wave and queue); entries
+// for the most its material can ask for is reserved first (one atomic per wave); entries
 // the hit did not use after all are marked as holes (ray flags bit 3 / shadow slot RT_NO_SLOT) and
-// cost the next generation one skipped thread each.
+// cost the next generation one skipped thread each.  The query's colour term goes to the
+// accumulators at once (wave_accumulate).
+// LDS: [small scene tables][per wave 64 x 10 words of staging]
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     const DScene sc = localise_scene(gsc, rt_lds_dynamic);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * 640u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     const uint32_t nq = nr + nsh;
-    const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: the queue allocation is a wave operation
+    const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: reservation and accumulation are wave operations
     Work<COUNT> wk = {};
     for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
         bool shade = false;
         uint32_t want_rays = 0, want_shadows = 0, inst = 0;
+        uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
+        d3 cval = mk3(0.0, 0.0, 0.0);
         if (ql < nq) {
             if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
                 if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
-                    a.contrib.U(2 * cap, CQ_SLOT, cap + q) = a.shadows.U(cap, SQ_SLOT, q);
-                    a.contrib.st3(2 * cap, CQ_C, cap + q, a.shadows.ld3(cap, SQ_W, q));
+                    cslot = a.shadows.U(cap, SQ_SLOT, q);
+                    cval = a.shadows.ld3(cap, SQ_W, q);
                     RT_COUNT(wk, shade_evals);
                 }
             } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
                 if (!a.rjobs.U(cap, JQ_FOUND, q)) {
-                    const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
-                    a.contrib.U(2 * cap, CQ_SLOT, q) = slot;
-                    a.contrib.st3(2 * cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q)));
-                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
+                    cslot = a.rays.U(cap, RQ_SLOT, q);
+                    cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
+                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
                 } else {
                     shade = true;
                     inst = a.rjobs.U(cap, JQ_INST, q);
@@ -489,50 +530,52 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
         // room in the next generation for what the hit may ask for
         uint32_t rbase, sbase;
         wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
-        if (!shade) continue;
-        if (rbase + want_rays > a.sub) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub ? a.sub - rbase : 0u; }
-        if (sbase + want_shadows > a.sub) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub ? a.sub - sbase : 0u; }
-        QueueSink sink;
-        sink.ray0 = sq * a.sub + rbase; sink.shadow0 = sq * a.sub + sbase;
-        const d3 ro = a.rays.ld3(cap, RQ_O, q), rd = a.rays.ld3(cap, RQ_D, q), rw = a.rays.ld3(cap, RQ_W, q), rc = a.rays.ld3(cap, RQ_C, q);
-        const uint32_t rdepth = a.rays.U(cap, RQ_DEPTH, q), rpath = a.rays.U(cap, RQ_PATH, q);
-        const uint32_t rslot = a.rays.U(cap, RQ_SLOT, q), rflags = a.rays.U(cap, RQ_FLAGS, q);
-        SceneHit h;
-        h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
-        h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
-        WorldHit wh;
-        wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
-        if (!(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
-        const DInstance& in = sc.instances[inst];
-        if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
-        sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
-        sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
-        sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0;
-        d3 local = wh.p;
-        if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
-        a.contrib.U(2 * cap, CQ_SLOT, q) = rslot;
-        a.contrib.st3(2 * cap, CQ_C, q, rw * local);
-        for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
-        for (uint32_t i = sink.nshadows; i < want_shadows; ++i) a.out_shadows.U(cap, SQ_SLOT, sink.shadow_entry(i)) = RT_NO_SLOT;
+        if (shade) {
+            if (rbase + want_rays > a.sub) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub ? a.sub - rbase : 0u; }
+            if (sbase + want_shadows > a.sub) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub ? a.sub - sbase : 0u; }
+            QueueSink sink;
+            sink.ray0 = sq * a.sub + rbase; sink.shadow0 = sq * a.sub + sbase;
+            const d3 ro = a.rays.ld3(cap, RQ_O, q), rd = a.rays.ld3(cap, RQ_D, q), rw = a.rays.ld3(cap, RQ_W, q), rc = a.rays.ld3(cap, RQ_C, q);
+            const uint32_t rdepth = a.rays.U(cap, RQ_DEPTH, q), rpath = a.rays.U(cap, RQ_PATH, q);
+            const uint32_t rslot = a.rays.U(cap, RQ_SLOT, q), rflags = a.rays.U(cap, RQ_FLAGS, q);
+            SceneHit h;
+            h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
+            h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
+            WorldHit wh;
+            wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
+            if (!(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
+            const DInstance& in = sc.instances[inst];
+            if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
+            sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
+            sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
+            sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0;
+            d3 local = wh.p;
+            if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
+            cslot = rslot;
+            cval = rw * local;
+            for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
+            for (uint32_t i = sink.nshadows; i < want_shadows; ++i) a.out_shadows.U(cap, SQ_SLOT, sink.shadow_entry(i)) = RT_NO_SLOT;
+        }
+        wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
 
-// ------------------------------------------------------------------ accumulation
-// One thread per (contribution, limb): the nine limbs of one sample are adjacent words, so the
-// atomics of nine neighbouring lanes fall into one or two cache lines.
+// ------------------------------------------------------------------ accumulation of the analytic phase's terms
+// Sky-box scenes only: the background seen by rays that failed the cast_ray gate (k_wf_analytic).
+// One thread per (ray, limb): the nine limbs of one sample are adjacent words.
 __global__ void __launch_bounds__(256)
 k_wf_accumulate(WfArgs a) {
     const uint32_t sq = blockIdx.x % RT_WF_Q;
-    const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
-    const uint32_t tasks = (nr + nsh) * RT_ACC_LIMBS;
+    const uint32_t nr = min(a.n_in[2 * sq], a.sub);
+    const uint32_t tasks = nr * RT_ACC_LIMBS;
     for (uint32_t t = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; t < tasks; t += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const uint32_t ql = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
-        const uint32_t e = ql < nr ? sq * a.sub + ql : a.cap + sq * a.sub + (ql - nr);
-        const uint32_t slot = a.contrib.U(2 * a.cap, CQ_SLOT, e);
+        const uint32_t e = sq * a.sub + ql;
+        const uint32_t slot = a.contrib.U(a.cap, CQ_SLOT, e);
         if (slot == RT_NO_SLOT) continue;
         const uint32_t channel = limb / 3u, part = limb % 3u;
-        const double v = a.contrib.F(2 * a.cap, CQ_C + channel, e);
+        const double v = a.contrib.F(a.cap, CQ_C + channel, e);
         if (!(fabs(v) < 0x1p40)) {
             if (part == 0) {
                 uint32_t bit = (v != v) ? 4u : (v > 0.0 ? 1u : 2u);
