@@ -681,7 +681,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             const char* names[8] = {"trips", "phase A jobs", "walk descend", "walk refill", "walk leaf", "phase B rays", "", ""};
             for (int i = 0; i < 6; ++i)
                 std::fprintf(stderr, "[rt] %-14s wave trips %12llu  lanes/trip %5.1f\n", names[i], c.prof[2 * i], c.prof[2 * i] ? (double)c.prof[2 * i + 1] / (double)c.prof[2 * i] : 0.0);
-            double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]);
+            double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]) + 1e-30;
             std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
                          100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
         }

@@ -141,7 +141,11 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
     }
     const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
     const d3 cam_o = ld3(rp.cam.origin);
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+    // thread t writes entry t % per of sub-queue t / per: neighbouring lanes fill neighbouring entries
+    const uint32_t per = (total + RT_WF_Q - 1u) / RT_WF_Q;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < per * RT_WF_Q; t += gridDim.x * blockDim.x) {
+        const uint32_t item = (t % per) * RT_WF_Q + t / per;
+        if (item >= total) continue;
         d3 dir;
         uint32_t slot;
         if (a.mode == 0) {
@@ -344,6 +348,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                 }
             }
             if (need && have) {
+                RT_PROF(wk, PF_T_REFILLS, PF_T_REFILL_LANES);
                 do {   // next mesh instance whose bounding box the ray reaches
                     inst = sc.mesh_instances[m];
                     const DInstance& in = sc.instances[inst];
@@ -372,6 +377,7 @@ k_wf_walk(DScene sc, WfArgs a) {
             bool h0, h1;
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
+            RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
                 const LBvhNode& n = lnodes[cur];
                 h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
@@ -393,6 +399,7 @@ k_wf_walk(DScene sc, WfArgs a) {
         }
         if (walking) {
             if (cur != RT_WALK_DONE) {                                // the leaf's triangles
+                RT_PROF(wk, PF_T_LEAF_ITERS, PF_T_LEAF_LANES);
                 uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
