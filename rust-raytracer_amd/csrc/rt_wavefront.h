@@ -462,6 +462,7 @@ RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32
 // `stage` is the wave's own 64 x 10 words of LDS.  Every lane of the wave must call.
 RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags) {
     const uint32_t lane = threadIdx.x & 63u;
+    if (!__ballot(slot != RT_NO_SLOT)) return;
     const double v[3] = {c.x, c.y, c.z};
     for (int ch = 0; ch < 3; ++ch) {
         double l0 = 0.0, l1 = 0.0, l2 = 0.0;
@@ -496,47 +497,81 @@ RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsi
 // the hit did not use after all are marked as holes (ray flags bit 3 / shadow slot RT_NO_SLOT) and
 // cost the next generation one skipped thread each.  The query's colour term goes to the
 // accumulators at once (wave_accumulate).
-// LDS: [small scene tables][per wave 64 x 10 words of staging]
+// A workgroup takes 256 queries at a time.  Each thread first settles its own query if that needs
+// no material (shadow tests, misses, holes); the hits are then dealt out again so that threads
+// that shade sit side by side: materials that spawn no rays from thread 0 upwards, the others
+// from thread 255 downwards, in query order.  Waves whose threads got no hit skip the shading.
+// LDS: [small scene tables][per wave 64 x 10 words of staging][256 x u16 hit list][4 x 2 wave counts]
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     const DScene sc = localise_scene(gsc, rt_lds_dynamic);
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * 640u;
+    unsigned long long* stage0 = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u));
+    unsigned long long* stage = stage0 + (threadIdx.x >> 6) * 640u;
+    uint16_t* list = reinterpret_cast<uint16_t*>(stage0 + 4u * 640u);
+    uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     const uint32_t nq = nr + nsh;
-    const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: reservation and accumulation are wave operations
     Work<COUNT> wk = {};
-    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
-        const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
-        bool shade = false;
-        uint32_t want_rays = 0, want_shadows = 0, inst = 0;
-        uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
-        d3 cval = mk3(0.0, 0.0, 0.0);
-        if (ql < nq) {
-            if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
-                if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
-                    cslot = a.shadows.U(cap, SQ_SLOT, q);
-                    cval = a.shadows.ld3(cap, SQ_W, q);
-                    RT_COUNT(wk, shade_evals);
-                }
-            } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
-                if (!a.rjobs.U(cap, JQ_FOUND, q)) {
-                    cslot = a.rays.U(cap, RQ_SLOT, q);
-                    cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
-                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
-                } else {
-                    shade = true;
-                    inst = a.rjobs.U(cap, JQ_INST, q);
-                    const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
-                    want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
+    // whole workgroups stay in the loop: it holds barriers
+    for (uint32_t w0 = (blockIdx.x / RT_WF_Q) * 256u; w0 < nq; w0 += (gridDim.x / RT_WF_Q) * 256u) {
+        uint32_t tot1 = 0, tot2 = 0;                                   // hits of the two kinds in this workgroup's window
+        {   // the thread's own query
+            const uint32_t ql = w0 + threadIdx.x;
+            const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
+            uint32_t cls = 0;
+            uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
+            d3 cval = mk3(0.0, 0.0, 0.0);
+            if (ql < nq) {
+                if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
+                    if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
+                        cslot = a.shadows.U(cap, SQ_SLOT, q);
+                        cval = a.shadows.ld3(cap, SQ_W, q);
+                        RT_COUNT(wk, shade_evals);
+                    }
+                } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
+                    if (!a.rjobs.U(cap, JQ_FOUND, q)) {
+                        cslot = a.rays.U(cap, RQ_SLOT, q);
+                        cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
+                        if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
+                    } else {
+                        const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
+                        cls = (bounds & 0xFFFFu) ? 2u : 1u;
+                    }
                 }
             }
+            const unsigned long long b1 = __ballot(cls == 1u), b2 = __ballot(cls == 2u);
+            if (lane == 0u) { wcount[2 * wave] = __popcll(b1); wcount[2 * wave + 1] = __popcll(b2); }
+            wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
+            __syncthreads();
+            uint32_t before1 = 0, before2 = 0;
+            for (uint32_t w = 0; w < 4u; ++w) {
+                const uint32_t c1 = wcount[2 * w], c2 = wcount[2 * w + 1];
+                if (w < wave) { before1 += c1; before2 += c2; }
+                tot1 += c1; tot2 += c2;
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (cls == 1u) list[before1 + __popcll(b1 & below)] = (uint16_t)threadIdx.x;
+            if (cls == 2u) list[255u - (before2 + __popcll(b2 & below))] = (uint16_t)threadIdx.x;
+            __syncthreads();
+        }
+        const bool shade = threadIdx.x < tot1 || threadIdx.x >= 256u - tot2;
+        if (!__ballot(shade)) continue;                                  // the wave's threads got no hit
+        uint32_t want_rays = 0, want_shadows = 0, inst = 0, q = 0;
+        if (shade) {
+            q = sq * a.sub + w0 + list[threadIdx.x];                      // hits are rays: ql < nr
+            inst = a.rjobs.U(cap, JQ_INST, q);
+            const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
+            want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
         }
         // room in the next generation for what the hit may ask for
         uint32_t rbase, sbase;
         wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
+        uint32_t cslot = RT_NO_SLOT;
+        d3 cval = mk3(0.0, 0.0, 0.0);
         if (shade) {
             if (rbase + want_rays > a.sub) { atomicAdd(a.dropped, want_rays); want_rays = rbase < a.sub ? a.sub - rbase : 0u; }
             if (sbase + want_shadows > a.sub) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub ? a.sub - sbase : 0u; }
