@@ -233,7 +233,7 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 // ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
-    uint32_t lds = ds.hot_bytes;   // the scene's small tables
+    uint32_t lds = ((ds.hot_bytes + 15u) & ~15u) + 512u + 32u;   // the scene's small tables, the dealt-out list, wave counts
     if (which == 1) lds = ((ds.hot_bytes + 15u) & ~15u) + 4u * 640u * 8u + 512u + 32u;   // + accumulation staging of the four waves, hit list, wave counts
     if (which == 1) { const char* e = std::getenv("RT_SHADE_LDS_PAD"); if (e) lds = std::max(lds, (uint32_t)std::atoi(e)); }   // occupancy experiments
     if (lds > 48u * 1024u) {

@@ -173,31 +173,79 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ dealing work out within a workgroup
+// The 256 threads of a workgroup each hold an item of kind 0 (nothing to do), 1 or 2.  Afterwards
+// list[0 .. tot1) names the threads with kind-1 items and list[256 - tot2 .. 256) those with kind-2
+// items, both in thread order, so that thread t can take over the item of thread list[t]: threads
+// with work sit side by side, the two kinds in different waves as far as they fit, and waves left
+// without work can skip it.  `list` (256 x u16) and `wcount` (4 x 2 words) are LDS.  Two barriers:
+// every thread of the workgroup must call, and a caller may write neither array before all its
+// threads have read `list` (the next call's writes to `list` come after its first barrier).
+RT_DEV void wg_deal(uint32_t kind, uint16_t* list, uint32_t* wcount, uint32_t& tot1, uint32_t& tot2) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long b1 = __ballot(kind == 1u), b2 = __ballot(kind == 2u);
+    if (lane == 0u) { wcount[2 * wave] = __popcll(b1); wcount[2 * wave + 1] = __popcll(b2); }
+    __syncthreads();
+    uint32_t before1 = 0, before2 = 0;
+    tot1 = 0; tot2 = 0;
+    for (uint32_t w = 0; w < 4u; ++w) {
+        const uint32_t c1 = wcount[2 * w], c2 = wcount[2 * w + 1];
+        if (w < wave) { before1 += c1; before2 += c2; }
+        tot1 += c1; tot2 += c2;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (kind == 1u) list[before1 + __popcll(b1 & below)] = (uint16_t)threadIdx.x;
+    if (kind == 2u) list[255u - (before2 + __popcll(b2 & below))] = (uint16_t)threadIdx.x;
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ analytic phase
+// A workgroup takes 256 queue entries at a time; the entries that hold a query (the others are
+// holes left by the shading phase) are dealt out again (wg_deal): rays from thread 0 upwards,
+// shadow tests from thread 255 downwards.
+// LDS: [small scene tables][256 x u16 list][4 x 2 wave counts]
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     const DScene sc = localise_scene(gsc, rt_lds_dynamic);
+    uint16_t* list = reinterpret_cast<uint16_t*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u));
+    uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
-    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
+    // whole workgroups stay in the loop: it holds barriers
+    for (uint32_t w0 = (blockIdx.x / RT_WF_Q) * 256u; w0 < nr + nsh; w0 += (gridDim.x / RT_WF_Q) * 256u) {
+        uint32_t kind = 0;
+        {
+            const uint32_t ql = w0 + threadIdx.x;
+            if (ql < nr) {
+                const uint32_t q = sq * a.sub + ql;
+                if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
+                if (a.rays.U(cap, RQ_FLAGS, q) & 8u) a.rjobs.U(cap, JQ_FLAGS, q) = 6u;        // a hole
+                else kind = 1u;
+            } else if (ql < nr + nsh) {
+                const uint32_t q = sq * a.sub + ql - nr;
+                if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) a.sjobs.U(cap, JQ_FLAGS, q) = 7u;   // a hole
+                else kind = 2u;
+            }
+        }
+        uint32_t tot1, tot2;
+        wg_deal(kind, list, wcount, tot1, tot2);
+        if (!(threadIdx.x < tot1 || threadIdx.x >= 256u - tot2)) continue;
+        const uint32_t ql = w0 + list[threadIdx.x];
         const bool shadow = ql >= nr;
         const uint32_t q = sq * a.sub + (shadow ? ql - nr : ql);      // entry of the shadow-test / ray arrays
         const WfQueue& jobs = shadow ? a.sjobs : a.rjobs;
         d3 o, d;
         double max_distance = 0.0;
         if (shadow) {
-            if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { jobs.U(cap, JQ_FLAGS, q) = 7u; continue; }        // a hole
             o = a.shadows.ld3(cap, SQ_O, q); d = a.shadows.ld3(cap, SQ_D, q); max_distance = a.shadows.F(cap, SQ_DIST, q);
             RT_COUNT(wk, rays_shadow);
         } else {
             const uint32_t flags = a.rays.U(cap, RQ_FLAGS, q);
-            if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
-            if (flags & 8u) { jobs.U(cap, JQ_FLAGS, q) = 6u; continue; }   // a hole
             o = a.rays.ld3(cap, RQ_O, q); d = a.rays.ld3(cap, RQ_D, q);
             const d3 rc = a.rays.ld3(cap, RQ_C, q);
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
@@ -500,7 +548,7 @@ RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsi
 // A workgroup takes 256 queries at a time.  Each thread first settles its own query if that needs
 // no material (shadow tests, misses, holes); the hits are then dealt out again so that threads
 // that shade sit side by side: materials that spawn no rays from thread 0 upwards, the others
-// from thread 255 downwards, in query order.  Waves whose threads got no hit skip the shading.
+// from thread 255 downwards (wg_deal).  Waves whose threads got no hit skip the shading.
 // LDS: [small scene tables][per wave 64 x 10 words of staging][256 x u16 hit list][4 x 2 wave counts]
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
@@ -510,7 +558,6 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     unsigned long long* stage = stage0 + (threadIdx.x >> 6) * 640u;
     uint16_t* list = reinterpret_cast<uint16_t*>(stage0 + 4u * 640u);
     uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
@@ -543,20 +590,8 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
                     }
                 }
             }
-            const unsigned long long b1 = __ballot(cls == 1u), b2 = __ballot(cls == 2u);
-            if (lane == 0u) { wcount[2 * wave] = __popcll(b1); wcount[2 * wave + 1] = __popcll(b2); }
             wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
-            __syncthreads();
-            uint32_t before1 = 0, before2 = 0;
-            for (uint32_t w = 0; w < 4u; ++w) {
-                const uint32_t c1 = wcount[2 * w], c2 = wcount[2 * w + 1];
-                if (w < wave) { before1 += c1; before2 += c2; }
-                tot1 += c1; tot2 += c2;
-            }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (cls == 1u) list[before1 + __popcll(b1 & below)] = (uint16_t)threadIdx.x;
-            if (cls == 2u) list[255u - (before2 + __popcll(b2 & below))] = (uint16_t)threadIdx.x;
-            __syncthreads();
+            wg_deal(cls, list, wcount, tot1, tot2);
         }
         const bool shade = threadIdx.x < tot1 || threadIdx.x >= 256u - tot2;
         if (!__ballot(shade)) continue;                                  // the wave's threads got no hit
