@@ -233,9 +233,10 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 // ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
+    // which: 0 analytic, 1 shade, 2 settle
     uint32_t lds = ((ds.hot_bytes + 15u) & ~15u) + 512u + 32u;   // the scene's small tables, the dealt-out list, wave counts
-    if (which == 1) lds = ((ds.hot_bytes + 15u) & ~15u) + 4u * 640u * 8u + 512u + 32u;   // + accumulation staging of the four waves, hit list, wave counts
-    if (which == 1) { const char* e = std::getenv("RT_SHADE_LDS_PAD"); if (e) lds = std::max(lds, (uint32_t)std::atoi(e)); }   // occupancy experiments
+    if (which == 1) lds = ((ds.hot_bytes + 15u) & ~15u) + 4u * 640u * 8u;   // the tables + accumulation staging of the four waves
+    if (which == 2) lds = 4u * 640u * 8u;
     if (lds > 48u * 1024u) {
         const void* fn = which == 0 ? (count ? (const void*)k_wf_analytic<F, true> : (const void*)k_wf_analytic<F, false>)
                                     : (count ? (const void*)k_wf_shade<F, true> : (const void*)k_wf_shade<F, false>);
@@ -244,9 +245,12 @@ int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, 
     if (which == 0) {
         if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
         else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-    } else {
+    } else if (which == 1) {
         if (count) hipLaunchKernelGGL((k_wf_shade<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
         else hipLaunchKernelGGL((k_wf_shade<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
+    } else {
+        if (count) hipLaunchKernelGGL((k_wf_settle<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
+        else hipLaunchKernelGGL((k_wf_settle<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));
@@ -286,7 +290,8 @@ int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScen
 constexpr uint32_t WF_MAX_GEN = RT_MAX_ROUNDS + 2;
 constexpr uint32_t WF_N = 0, WF_WALK_COUNT = WF_N + 2 * RT_WF_Q * (WF_MAX_GEN + 1), WF_WALK_NEXT = WF_WALK_COUNT + RT_WF_Q * (WF_MAX_GEN + 1),
                    WF_PASS_WORDS = WF_WALK_NEXT + RT_WF_Q * (WF_MAX_GEN + 1);
-constexpr uint32_t WF_DROPPED = 2 * WF_PASS_WORDS;
+constexpr uint32_t WF_HIT_COUNT = 2 * WF_PASS_WORDS;            // per pass 2 * RT_WF_Q * (WF_MAX_GEN + 1) words
+constexpr uint32_t WF_DROPPED = WF_HIT_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1);
 constexpr size_t WF_SCALAR_BYTES = (WF_DROPPED + 4) * 4;
 // RT_PATH=persistent forces the persistent kernel for every scene (read at every frame, so that a
 // test can render the same scene down both schedules in one process).
@@ -506,12 +511,15 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
             wa.rays = queue(s->wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(s->wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
             wa.out_rays = queue(s->wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
             wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g; wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g;
+            wa.hit_count = (unsigned int*)s->wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             int lrc = wf_launch(0, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
             if (lrc != RT_OK) return lrc;
             if (s->ds.features & RTF_MESH) {
                 lrc = wf_launch_walk(count_work, (uint32_t)s->num_cus, stream, s->ds, wa);
                 if (lrc != RT_OK) return lrc;
             }
+            lrc = wf_launch(2, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
+            if (lrc != RT_OK) return lrc;
             lrc = wf_launch(1, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
             if (lrc != RT_OK) return lrc;
             if (s->ds.has_background) {

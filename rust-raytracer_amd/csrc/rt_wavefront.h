@@ -62,6 +62,10 @@ struct WfArgs {
     uint32_t* walk_list;              // RT_WF_Q lists of 2*sub query ids: ray i -> i, shadow test i -> i | 0x80000000
     unsigned int* walk_count;         // per list
     unsigned int* walk_next;          // cursor into the lists read as one
+    // hits to shade (k_wf_settle -> k_wf_shade): per sub-queue a list of ray entries in the first `sub` words of
+    // its walk list (free again after the walk); materials that spawn no rays from the front, the
+    // others from the back; hit_count[2s], hit_count[2s+1] (one 64-bit word) count the two kinds
+    unsigned int* hit_count;
     uint32_t* walk_overflow;          // (RT_BVH_STACK - RT_WF_LDS_STACK) words per walk thread
     uint32_t refill_min;
     // outputs
@@ -540,64 +544,79 @@ RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsi
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// A hit's new rays and shadow tests are written straight into the next generation's queues.  Room
-// for the most its material can ask for is reserved first (one atomic per wave); entries
-// the hit did not use after all are marked as holes (ray flags bit 3 / shadow slot RT_NO_SLOT) and
-// cost the next generation one skipped thread each.  The query's colour term goes to the
-// accumulators at once (wave_accumulate).
-// A workgroup takes 256 queries at a time.  Each thread first settles its own query if that needs
-// no material (shadow tests, misses, holes); the hits are then dealt out again so that threads
-// that shade sit side by side: materials that spawn no rays from thread 0 upwards, the others
-// from thread 255 downwards (wg_deal).  Waves whose threads got no hit skip the shading.
-// LDS: [small scene tables][per wave 64 x 10 words of staging][256 x u16 hit list][4 x 2 wave counts]
+// First the queries that need no material are settled (k_wf_settle, a light kernel at high
+// occupancy), then the hits are shaded (k_wf_shade, register-heavy) from a list in which they sit
+// side by side, so that its waves are full and of one kind of material.
+//
+// k_wf_settle: one thread per queue entry.  Shadow tests that nothing blocks and rays that left
+// the scene give their colour term to the accumulators at once (wave_accumulate); hits go onto the
+// sub-queue's hit list.  LDS: [per wave 64 x 10 words of staging]
 template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
-k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
-    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
-    unsigned long long* stage0 = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u));
-    unsigned long long* stage = stage0 + (threadIdx.x >> 6) * 640u;
-    uint16_t* list = reinterpret_cast<uint16_t*>(stage0 + 4u * 640u);
-    uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
+k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic) + (threadIdx.x >> 6) * 640u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     const uint32_t nq = nr + nsh;
+    const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: reservation and accumulation are wave operations
+    uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
-    // whole workgroups stay in the loop: it holds barriers
-    for (uint32_t w0 = (blockIdx.x / RT_WF_Q) * 256u; w0 < nq; w0 += (gridDim.x / RT_WF_Q) * 256u) {
-        uint32_t tot1 = 0, tot2 = 0;                                   // hits of the two kinds in this workgroup's window
-        {   // the thread's own query
-            const uint32_t ql = w0 + threadIdx.x;
-            const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
-            uint32_t cls = 0;
-            uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
-            d3 cval = mk3(0.0, 0.0, 0.0);
-            if (ql < nq) {
-                if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
-                    if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
-                        cslot = a.shadows.U(cap, SQ_SLOT, q);
-                        cval = a.shadows.ld3(cap, SQ_W, q);
-                        RT_COUNT(wk, shade_evals);
-                    }
-                } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
-                    if (!a.rjobs.U(cap, JQ_FOUND, q)) {
-                        cslot = a.rays.U(cap, RQ_SLOT, q);
-                        cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
-                        if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
-                    } else {
-                        const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
-                        cls = (bounds & 0xFFFFu) ? 2u : 1u;
-                    }
+    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
+        const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
+        uint32_t kind = 0;
+        uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
+        d3 cval = mk3(0.0, 0.0, 0.0);
+        if (ql < nq) {
+            if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
+                if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
+                    cslot = a.shadows.U(cap, SQ_SLOT, q);
+                    cval = a.shadows.ld3(cap, SQ_W, q);
+                    RT_COUNT(wk, shade_evals);
+                }
+            } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
+                if (!a.rjobs.U(cap, JQ_FOUND, q)) {
+                    cslot = a.rays.U(cap, RQ_SLOT, q);
+                    cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
+                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
+                } else {
+                    const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
+                    kind = (bounds & 0xFFFFu) ? 2u : 1u;
                 }
             }
-            wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
-            wg_deal(cls, list, wcount, tot1, tot2);
         }
-        const bool shade = threadIdx.x < tot1 || threadIdx.x >= 256u - tot2;
-        if (!__ballot(shade)) continue;                                  // the wave's threads got no hit
+        uint32_t at1, at2;
+        wave_alloc2(a.hit_count + 2 * sq, kind == 1u ? 1u : 0u, kind == 2u ? 1u : 0u, at1, at2);
+        if (kind == 1u) hits[at1] = ql;                               // (hits are rays: ql < nr <= sub, and there are at most nr of them)
+        if (kind == 2u) hits[a.sub - 1u - at2] = ql;
+        wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
+    }
+    if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
+}
+
+// k_wf_shade: one thread per hit.  A hit's new rays and shadow tests are written straight into the
+// next generation's queues.  Room for the most its material can ask for is reserved first (one
+// atomic per wave); entries the hit did not use after all are marked as holes (ray flags bit 3 /
+// shadow slot RT_NO_SLOT) and cost the next generation one skipped thread each.  The hit's own
+// colour term goes to the accumulators at once.
+// LDS: [small scene tables][per wave 64 x 10 words of staging]
+template <uint32_t F, bool COUNT>
+__global__ void __launch_bounds__(256)
+k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
+    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * 640u;
+    const uint32_t sq = blockIdx.x % RT_WF_Q;
+    const uint32_t cap = a.cap;
+    const uint32_t n1 = min(a.hit_count[2 * sq], a.sub), n2 = min(a.hit_count[2 * sq + 1], a.sub - n1);
+    const uint32_t r1 = (n1 + 63u) & ~63u;                            // the second kind starts in a wave of its own
+    const uint32_t rounded = (r1 + n2 + 63u) & ~63u;
+    const uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
+    Work<COUNT> wk = {};
+    for (uint32_t v = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; v < rounded; v += (gridDim.x / RT_WF_Q) * blockDim.x) {
+        const bool shade = v < n1 || (v >= r1 && v - r1 < n2);
         uint32_t want_rays = 0, want_shadows = 0, inst = 0, q = 0;
         if (shade) {
-            q = sq * a.sub + w0 + list[threadIdx.x];                      // hits are rays: ql < nr
+            q = sq * a.sub + (v < n1 ? hits[v] : hits[a.sub - 1u - (v - r1)]);
             inst = a.rjobs.U(cap, JQ_INST, q);
             const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
             want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
