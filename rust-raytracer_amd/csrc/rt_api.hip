@@ -234,24 +234,20 @@ constexpr uint32_t RT_MAX_ROUNDS = 40;
 template <uint32_t F>
 int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
     // which: 0 analytic, 1 shade, 2 settle
-    uint32_t lds = ((ds.hot_bytes + 15u) & ~15u) + 512u + 32u;   // the scene's small tables, the dealt-out list, wave counts
-    if (which == 1) lds = ((ds.hot_bytes + 15u) & ~15u) + 4u * 640u * 8u;   // the tables + accumulation staging of the four waves
+    const bool hot = ds.hot_bytes > 0;                                 // the scene's small tables fit into LDS
+    const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
+    uint32_t lds = tables + 512u + 32u;                                // + the dealt-out list, wave counts
+    if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
     if (which == 2) lds = 4u * 640u * 8u;
-    if (lds > 48u * 1024u) {
-        const void* fn = which == 0 ? (count ? (const void*)k_wf_analytic<F, true> : (const void*)k_wf_analytic<F, false>)
-                                    : (count ? (const void*)k_wf_shade<F, true> : (const void*)k_wf_shade<F, false>);
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (which == 0) {
-        if (count) hipLaunchKernelGGL((k_wf_analytic<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-        else hipLaunchKernelGGL((k_wf_analytic<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-    } else if (which == 1) {
-        if (count) hipLaunchKernelGGL((k_wf_shade<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-        else hipLaunchKernelGGL((k_wf_shade<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-    } else {
-        if (count) hipLaunchKernelGGL((k_wf_settle<F, true>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-        else hipLaunchKernelGGL((k_wf_settle<F, false>), dim3(grid), dim3(256), lds, stream, ds, rp, wa);
-    }
+    const void* fn;
+    if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true> : (const void*)k_wf_analytic<F, false, true>)
+                             : (count ? (const void*)k_wf_analytic<F, true, false> : (const void*)k_wf_analytic<F, false, false>);
+    else if (which == 1) fn = hot ? (count ? (const void*)k_wf_shade<F, true, true> : (const void*)k_wf_shade<F, false, true>)
+                                  : (count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>);
+    else fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
+    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void* params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
+    (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
@@ -692,6 +688,14 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]) + 1e-30;
             std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
                          100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
+        }
+        if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work && s->last_used_queues) {   // where the shade kernel's waves spend their time
+            DCounters c{};
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            const double it = (double)c.prof[PF_TRIPS] + 1e-30;
+            std::fprintf(stderr, "[rt] shade: %llu wave trips, %.1f hits each; cycles per trip: list+instance %.0f, reservation %.0f, ray+world hit %.0f, material %.0f, holes %.0f, accumulation %.0f; start-up %llu\n",
+                         c.prof[PF_TRIPS], (double)c.prof[PF_TRIP_LANES] / it, c.prof[PF_A_ITERS] / it, c.prof[PF_A_LANES] / it, c.prof[PF_B_ITERS] / it,
+                         c.prof[PF_B_LANES] / it, c.prof[PF_CYC_A] / it, c.prof[PF_CYC_T] / it, c.prof[PF_CYC_FETCH]);
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && s->wf_scalars.p && s->last_used_queues) {   // queue fill per generation
             std::vector<unsigned int> ws(WF_SCALAR_BYTES / 4);

@@ -300,7 +300,7 @@ RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_
 // PhongShader::get_color (src/shader/phong.rs:29-47).  Returns the part that is known now;
 // deferred point lights are appended to `spawn` as SHADOW entries.
 template <uint32_t F, bool COUNT, class SINK>
-RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, uint64_t stream, uint32_t path,
+RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_dir, d3 win, uint64_t stream, uint32_t path,
                       SINK& sink, Work<COUNT>& wk) {
     PhongCtx c;
     c.p = p; c.n = n; c.view = -1.0 * ray_dir;
@@ -326,7 +326,7 @@ RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_di
                 PhongCtx one = c;
                 one.total = mk3(0.0, 0.0, 0.0);
                 phong_lit(one, surface_dot, light_direction, intensity);
-                sink.shadow(p, light_direction, light_distance, one.total);
+                sink.shadow(p, light_direction, light_distance, win * one.total);
             }
         } else if constexpr (F & RTF_INLINE_LIGHTS) {
             if (L.kind == 1) {
@@ -378,6 +378,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         uint32_t shader, cursor, spawn_begin, child_spawn_begin;
         d3 acc;          // MIX: running product; COMPOSITE: running sum (local parts)
         d3 cin;          // contribution handed to this group
+        d3 win;          // weight of the group's value in the hit's colour (the product of the factors above it)
         d3 saved_n;      // CHAIN: normal to restore on exit
     };
     Frame fr[RT_SHADE_MAX_FRAMES];
@@ -385,13 +386,14 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
     d3 n = hit.n;
     uint32_t cur = root_shader;
     d3 cin = ray_contrib;
+    d3 win = mk3(1.0, 1.0, 1.0);                                  // new rays and shadow tests are given their final weight at once
     d3 value = mk3(0.0, 0.0, 0.0);
     for (;;) {
         // ---- enter `cur` with contribution `cin`
         const DShader& sh = sc.shaders[cur];
         bool returned = true;
         switch (sh.kind) {
-            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, stream, path, sink, wk); break;
+            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, win, stream, path, sink, wk); break;
             case DS_TEXTURE:                                                                  // shader/texture.rs:16-19
                 if constexpr (F & RTF_IMAGES) value = texture_color(sc, sh.ref, hit.u, hit.v); else value = mk3(0.0, 0.0, 0.0);
                 break;
@@ -400,30 +402,30 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 break;
             case DS_REFLECTION: {                                                             // shader/reflection.rs:14-18
                 d3 k = ld3(sh.p);
-                if (sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), k, cin * k, cur * 4 + 0);
+                if (sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), win * k, cin * k, cur * 4 + 0);
                 value = mk3(0.0, 0.0, 0.0);
                 break;
             }
             case DS_TRANSLUCENT: {                                                            // shader/translucent.rs:50-62
                 double kt, kr;
                 fresnel(ray_dir, n, sh.p[3], kt, kr);
-                if (kt > 0.0 && sink.room()) sink.ray(hit.p, transmit_dir(ray_dir, n, sh.p[3]), mk3(kt, kt, kt), cin * kt, cur * 4 + 1);
-                if (kr > 0.0 && sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), mk3(kr, kr, kr), cin * kr, cur * 4 + 2);
+                if (kt > 0.0 && sink.room()) sink.ray(hit.p, transmit_dir(ray_dir, n, sh.p[3]), win * kt, cin * kt, cur * 4 + 1);
+                if (kr > 0.0 && sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), win * kr, cin * kr, cur * 4 + 2);
                 value = mk3(0.0, 0.0, 0.0);
                 break;
             }
             default: {   // group shaders open a frame and descend into their first child
                 if (depth >= RT_SHADE_MAX_FRAMES || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
                 Frame& f = fr[depth++];
-                f.shader = cur; f.cursor = 0; f.spawn_begin = sink.mark(); f.child_spawn_begin = f.spawn_begin; f.cin = cin; f.saved_n = n;
+                f.shader = cur; f.cursor = 0; f.spawn_begin = sink.mark(); f.child_spawn_begin = f.spawn_begin; f.cin = cin; f.win = win; f.saved_n = n;
                 if (sh.kind == DS_MIX) {                                                      // shader.rs:66-69
                     f.acc = mk3(1.0, 1.0, 1.0);
                     cur = sc.shader_child_idx[sh.first_child];
-                    cin = f.cin * f.acc;
+                    cin = f.cin * f.acc; win = f.win * f.acc;
                 } else if (sh.kind == DS_COMPOSITE) {                                         // shader.rs:95-102
                     f.acc = mk3(0.0, 0.0, 0.0);
                     cur = sc.shader_child_idx[sh.first_child];
-                    cin = f.cin * sc.shader_child_weight[sh.first_child];
+                    cin = f.cin * sc.shader_child_weight[sh.first_child]; win = f.win * sc.shader_child_weight[sh.first_child];
                 } else {                                                                      // CHAIN shader.rs:134-152
                     if constexpr (F & RTF_IMAGES) {
                         for (uint32_t k = 0; k < sh.nm_count; ++k)
@@ -431,7 +433,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                     }
                     f.cursor = sh.num_children - 1;
                     cur = sc.shader_child_idx[sh.first_child + sh.num_children - 1];
-                    cin = f.cin;
+                    cin = f.cin; win = f.win;
                 }
                 returned = false;
                 break;
@@ -444,13 +446,11 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
             Frame& f = fr[depth - 1];
             const DShader& g = sc.shaders[f.shader];
             if (g.kind == DS_MIX) {
-                // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc
+                // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc (they were, through win)
                 sink.scale(f.spawn_begin, f.child_spawn_begin, value);
-                sink.scale(f.child_spawn_begin, sink.mark(), f.acc);
                 f.acc = f.acc * value;
             } else if (g.kind == DS_COMPOSITE) {
-                double w = sc.shader_child_weight[g.first_child + f.cursor];
-                sink.scale(f.child_spawn_begin, sink.mark(), w);
+                double w = sc.shader_child_weight[g.first_child + f.cursor];   // (the child's rays carry w already, through win)
                 f.acc = f.acc + w * value;
             } else {
                 f.acc = value;
@@ -460,6 +460,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 f.child_spawn_begin = sink.mark();
                 cur = sc.shader_child_idx[g.first_child + f.cursor];
                 cin = g.kind == DS_MIX ? f.cin * f.acc : f.cin * sc.shader_child_weight[g.first_child + f.cursor];
+                win = g.kind == DS_MIX ? f.win * f.acc : f.win * sc.shader_child_weight[g.first_child + f.cursor];
                 break;
             }
             value = f.acc;                                           // group finished

@@ -30,9 +30,14 @@ RT_DEV const uint8_t* rt_lds_base() { return rt_lds_dynamic + (size_t)RT_LDS_FIX
 // a scene description whose pointers to those tables lead into the copy.  The device code reads
 // them many times per ray, each read depending on the one before (instance -> primitive ->
 // shader -> child shader ...): out of LDS such a chain costs a fraction of what it costs out of L2.
+// HOT is a compile-time choice (false: the tables stay where they are, e.g. too large for LDS) so
+// that the compiler knows the address space of every table pointer: reads become LDS
+// instructions, which, unlike reads through pointers that may lead anywhere, do not have to wait
+// for the queue stores issued before them.
+template <bool HOT>
 RT_DEV DScene localise_scene(const DScene& sc, uint8_t* lds) {
     DScene l = sc;
-    if (sc.hot_bytes == 0) return l;
+    if (!HOT) return l;
     const uint4* src = reinterpret_cast<const uint4*>(sc.hot_blob);
     uint4* dst = reinterpret_cast<uint4*>(lds);
     for (uint32_t i = threadIdx.x; i < sc.hot_bytes / 16u; i += blockDim.x) dst[i] = src[i];

@@ -208,11 +208,11 @@ RT_DEV void wg_deal(uint32_t kind, uint16_t* list, uint32_t* wcount, uint32_t& t
 // holes left by the shading phase) are dealt out again (wg_deal): rays from thread 0 upwards,
 // shadow tests from thread 255 downwards.
 // LDS: [small scene tables][256 x u16 list][4 x 2 wave counts]
-template <uint32_t F, bool COUNT>
+template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
-    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
-    uint16_t* list = reinterpret_cast<uint16_t*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u));
+    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
+    uint16_t* list = reinterpret_cast<uint16_t*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u));
     uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
@@ -600,11 +600,11 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
 // shadow slot RT_NO_SLOT) and cost the next generation one skipped thread each.  The hit's own
 // colour term goes to the accumulators at once.
 // LDS: [small scene tables][per wave 64 x 10 words of staging]
-template <uint32_t F, bool COUNT>
+template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
-    const DScene sc = localise_scene(gsc, rt_lds_dynamic);
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + ((gsc.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * 640u;
+    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u)) + (threadIdx.x >> 6) * 640u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t cap = a.cap;
     const uint32_t n1 = min(a.hit_count[2 * sq], a.sub), n2 = min(a.hit_count[2 * sq + 1], a.sub - n1);
@@ -612,6 +612,8 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     const uint32_t rounded = (r1 + n2 + 63u) & ~63u;
     const uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
+    long long t_prof = COUNT ? clock64() : 0;
+    RT_PROF_CYC(wk, PF_CYC_FETCH, t_prof);                            // (start-up: the scene tables into LDS)
     for (uint32_t v = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; v < rounded; v += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const bool shade = v < n1 || (v >= r1 && v - r1 < n2);
         uint32_t want_rays = 0, want_shadows = 0, inst = 0, q = 0;
@@ -621,9 +623,12 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
             want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
         }
+        RT_PROF(wk, PF_TRIPS, PF_TRIP_LANES);
+        RT_PROF_CYC(wk, PF_A_ITERS, t_prof);                              // hit list, instance, material bounds
         // room in the next generation for what the hit may ask for
         uint32_t rbase, sbase;
         wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
+        RT_PROF_CYC(wk, PF_A_LANES, t_prof);                              // reservation
         uint32_t cslot = RT_NO_SLOT;
         d3 cval = mk3(0.0, 0.0, 0.0);
         if (shade) {
@@ -640,6 +645,7 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             WorldHit wh;
             wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
             if (!(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
+            RT_PROF_CYC(wk, PF_B_ITERS, t_prof);                          // the ray, the hit in world space
             const DInstance& in = sc.instances[inst];
             if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
             sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
@@ -649,10 +655,13 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
             cslot = rslot;
             cval = rw * local;
+            RT_PROF_CYC(wk, PF_B_LANES, t_prof);                          // material
             for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
             for (uint32_t i = sink.nshadows; i < want_shadows; ++i) a.out_shadows.U(cap, SQ_SLOT, sink.shadow_entry(i)) = RT_NO_SLOT;
         }
+        RT_PROF_CYC(wk, PF_CYC_A, t_prof);                                // holes
         wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
+        RT_PROF_CYC(wk, PF_CYC_T, t_prof);                                // accumulation
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
