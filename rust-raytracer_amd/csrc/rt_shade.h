@@ -381,7 +381,11 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         d3 win;          // weight of the group's value in the hit's colour (the product of the factors above it)
         d3 saved_n;      // CHAIN: normal to restore on exit
     };
-    Frame fr[RT_SHADE_MAX_FRAMES];
+    // The innermost open group is kept in `top` (registers); the groups around it wait in `below`.
+    // Materials with one level of grouping never touch `below`, whose dynamic indexing puts it into
+    // scratch memory: a scratch read has to wait for the queue stores issued before it.
+    Frame top;
+    Frame below[RT_SHADE_MAX_FRAMES - 1];
     int depth = 0;
     d3 n = hit.n;
     uint32_t cur = root_shader;
@@ -416,7 +420,9 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
             }
             default: {   // group shaders open a frame and descend into their first child
                 if (depth >= RT_SHADE_MAX_FRAMES || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
-                Frame& f = fr[depth++];
+                if (depth > 0) below[depth - 1] = top;
+                depth++;
+                Frame& f = top;
                 f.shader = cur; f.cursor = 0; f.spawn_begin = sink.mark(); f.child_spawn_begin = f.spawn_begin; f.cin = cin; f.win = win; f.saved_n = n;
                 if (sh.kind == DS_MIX) {                                                      // shader.rs:66-69
                     f.acc = mk3(1.0, 1.0, 1.0);
@@ -431,6 +437,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                         for (uint32_t k = 0; k < sh.nm_count; ++k)
                             n = perturbed_normal(sc, sc.normal_maps[sc.chain_nmaps[sh.nm_begin + k]], hit.u, hit.v, n, hit.tangent);
                     }
+                    f.acc = mk3(0.0, 0.0, 0.0);
                     f.cursor = sh.num_children - 1;
                     cur = sc.shader_child_idx[sh.first_child + sh.num_children - 1];
                     cin = f.cin; win = f.win;
@@ -443,7 +450,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         // ---- `value` (+ spawns since child_spawn_begin) returns to the enclosing frames
         for (;;) {
             if (depth == 0) return value;
-            Frame& f = fr[depth - 1];
+            Frame& f = top;
             const DShader& g = sc.shaders[f.shader];
             if (g.kind == DS_MIX) {
                 // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc (they were, through win)
@@ -466,6 +473,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
             value = f.acc;                                           // group finished
             n = f.saved_n;
             depth--;
+            if (depth > 0) top = below[depth - 1];
         }
     }
 }
