@@ -317,6 +317,10 @@ uint32_t refill_min() {
     static const uint32_t b = [] { const char* e = std::getenv("RT_REFILL_MIN"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min<long>(v, 64) : 16u; }();
     return b;
 }
+uint32_t descend_frac() {
+    static const uint32_t b = [] { const char* e = std::getenv("RT_DESCEND_FRAC"); long v = e ? std::atol(e) : 2; return (uint32_t)std::max<long>(0, std::min<long>(v, 8)); }();
+    return b;
+}
 uint32_t trace_rounds(uint32_t recursion_depth) {
     static const long forced = [] { const char* e = std::getenv("RT_TRACE_ROUNDS"); return e ? std::atol(e) : 0L; }();
     if (forced > 0) return (uint32_t)std::min<long>(forced, RT_MAX_ROUNDS);
@@ -483,7 +487,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
         wa.rjobs = queue(s->wf_rjobs, n, JQ_NF); wa.sjobs = queue(s->wf_sjobs, n, JQ_NF);
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
-        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min();
+        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min(); wa.descend_frac = descend_frac();
         wa.contrib = queue(s->wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;

@@ -68,6 +68,7 @@ struct WfArgs {
     unsigned int* hit_count;
     uint32_t* walk_overflow;          // (RT_BVH_STACK - RT_WF_LDS_STACK) words per walk thread
     uint32_t refill_min;
+    uint32_t descend_frac;            // eighths: the descent pauses for the leaves once fewer than this share of the walking lanes still descend (0: never)
     // outputs
     WfQueue contrib;                  // cap entries
     unsigned long long* acc;
@@ -424,7 +425,10 @@ k_wf_walk(DScene sc, WfArgs a) {
                 } while (!walking && have);
             }
         }
+        const uint32_t nwalk = (uint32_t)__popcll(__ballot(walking));
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
+            // (lanes still here: those descending) most of the wave waits at its leaves -> test those first
+            if ((uint32_t)__popcll(__ballot(true)) * 8u < nwalk * a.descend_frac) break;
             double tn0, tn1;
             bool h0, h1;
             uint32_t c0, c1;
@@ -450,7 +454,7 @@ k_wf_walk(DScene sc, WfArgs a) {
             else cur = pop();
         }
         if (walking) {
-            if (cur != RT_WALK_DONE) {                                // the leaf's triangles
+            if (cur != RT_WALK_DONE && (cur & 0x80000000u)) {         // the leaf's triangles
                 RT_PROF(wk, PF_T_LEAF_ITERS, PF_T_LEAF_LANES);
                 uint32_t base = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
                 for (uint32_t i = 0; i < cnt; ++i) {
