@@ -277,7 +277,22 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         jobs.U(cap, JQ_CA, q) = h.c.a; jobs.U(cap, JQ_CB, q) = h.c.b;
         jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
         if constexpr (HAS_MESH) {
-            if (!settled && sc.num_mesh_instances > 0) {
+            // Only queries whose ray reaches the bounding box of some mesh go on to the walk (the walk
+            // makes the same test, with the same numbers, first thing for every instance).
+            bool reaches = false;
+            if (!settled) {
+                const uint32_t nm = sc.num_mesh_instances;
+                for (uint32_t m = 0; m < nm && !reaches; ++m) {
+                    const DInstance& in = sc.instances[sc.mesh_instances[m]];
+                    const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
+                    double s, inv_s, tn;
+                    const LRay lr = to_local(in.x, o, d, s, inv_s);
+                    const d3 inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+                    reaches = slab(mesh.lo, mesh.hi, lr.o, inv, (shadow ? max_distance : h.t) * s, tn);
+                }
+                if (COUNT && !reaches) { wk.instance_tests += nm; wk.box_tests += nm; }   // what the walk would have counted
+            }
+            if (reaches) {
                 uint32_t w = wave_alloc(a.walk_count + sq);
                 a.walk_list[(size_t)sq * (2u * a.sub) + w] = shadow ? (q | 0x80000000u) : q;
             }
