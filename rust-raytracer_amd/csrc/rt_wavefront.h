@@ -83,7 +83,7 @@ struct WfArgs {
     const uint32_t* list;
     const unsigned int* aa_count;
     uint32_t mode;
-    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading
+    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
 };
 
 // The shader tree's rays go straight into the next generation's queues, at positions reserved beforehand.
@@ -100,6 +100,7 @@ struct QueueSink {
     d3 origin;                        // unused: every new ray starts at the hit point it is given
     d3 parent_w;                      // weight of the hit's own ray: new weights are products with it
     uint32_t depth, parent_path, slot;
+    bool dry;                         // timing experiments only (RT_WF_DEBUG bit 2): count the entries, store nothing
     bool drop_dead;                   // scene without a sky box: a ray that will fail the gate of Scene::cast_ray adds exactly nothing
     RT_DEV bool room() const { return true; }                      // the reservation covers the material's worst case
     RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
@@ -107,6 +108,7 @@ struct QueueSink {
         if (drop_dead && !(depth > 0 && (c.x + c.y + c.z) > RT_MIN_CONTRIBUTION)) return;   // scene.rs:67-73 with a BLACK background
         if (nrays >= max_rays) return;
         const uint32_t e = ray_entry(nrays++);
+        if (dry) return;
         rays.st3(cap, RQ_O, e, o); rays.st3(cap, RQ_D, e, d); rays.st3(cap, RQ_W, e, parent_w * w); rays.st3(cap, RQ_C, e, c);
         rays.U(cap, RQ_DEPTH, e) = depth; rays.U(cap, RQ_PATH, e) = child_path(parent_path, ordinal);
         rays.U(cap, RQ_SLOT, e) = slot; rays.U(cap, RQ_FLAGS, e) = 0u;
@@ -114,6 +116,7 @@ struct QueueSink {
     RT_DEV void shadow(d3 o, d3 d, double dist, d3 w) {
         if (nshadows >= max_shadows) return;
         const uint32_t e = shadow_entry(nshadows++);
+        if (dry) return;
         shadows.st3(cap, SQ_O, e, o); shadows.st3(cap, SQ_D, e, d); shadows.F(cap, SQ_DIST, e) = dist;
         shadows.st3(cap, SQ_W, e, parent_w * w); shadows.U(cap, SQ_SLOT, e) = slot;
     }
@@ -511,7 +514,9 @@ k_wf_walk(DScene sc, WfArgs a) {
 // Room for `nr` consecutive ray entries and `ns` consecutive shadow-test entries per calling lane;
 // both fill counters share one 64-bit word (rays low, shadow tests high) so that one atomic per
 // wave serves both queues.  Every lane of the wave must call (with zeros if it wants nothing).
-RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32_t& rbase, uint32_t& sbase) {
+// In two halves, so that work that does not need the answer can run while the atomic is under way.
+struct WaveAlloc2 { unsigned long long before, base; };
+RT_DEV WaveAlloc2 wave_alloc2_begin(unsigned int* counters, uint32_t nr, uint32_t ns) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long incl = (unsigned long long)nr | ((unsigned long long)ns << 32);
     const unsigned long long mine = incl;
@@ -520,11 +525,18 @@ RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32
         if ((int)lane >= off) incl += v;
     }
     const unsigned long long sum = __shfl(incl, 63);
-    unsigned long long base = 0;
-    if (lane == 63u && sum) base = atomicAdd(reinterpret_cast<unsigned long long*>(counters), sum);
-    base = __shfl(base, 63);
-    const unsigned long long at = base + incl - mine;
+    WaveAlloc2 w;
+    w.before = incl - mine;
+    w.base = 0;
+    if (lane == 63u && sum) w.base = atomicAdd(reinterpret_cast<unsigned long long*>(counters), sum);
+    return w;
+}
+RT_DEV void wave_alloc2_end(const WaveAlloc2& w, uint32_t& rbase, uint32_t& sbase) {
+    const unsigned long long at = __shfl(w.base, 63) + w.before;
     rbase = (uint32_t)at; sbase = (uint32_t)(at >> 32);
+}
+RT_DEV void wave_alloc2(unsigned int* counters, uint32_t nr, uint32_t ns, uint32_t& rbase, uint32_t& sbase) {
+    wave_alloc2_end(wave_alloc2_begin(counters, nr, ns), rbase, sbase);
 }
 
 // Adds one colour term per lane (slot RT_NO_SLOT: none) to the accumulators, the whole wave at once:
@@ -557,8 +569,13 @@ RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsi
     for (uint32_t t = lane; t < 64u * RT_ACC_LIMBS; t += 64u) {
         const uint32_t rec = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
         const uint32_t rslot = (uint32_t)stage[rec * 10u + 9u];
-        const unsigned long long l = stage[rec * 10u + limb];
-        if (rslot != RT_NO_SLOT && l != 0ull) atomicAdd(acc + (size_t)rslot * RT_ACC_LIMBS + limb, l);
+        // neighbouring lanes often hold terms of one sample (the shadow tests of one hit, the rays
+        // it spawned): the first of such a run adds the whole run's limbs up (integers: any order
+        // gives the same sum) and issues one atomic for them
+        if (rslot == RT_NO_SLOT || (rec > 0u && (uint32_t)stage[(rec - 1u) * 10u + 9u] == rslot)) continue;
+        unsigned long long l = stage[rec * 10u + limb];
+        for (uint32_t r = rec + 1u; r < 64u && (uint32_t)stage[r * 10u + 9u] == rslot; ++r) l += stage[r * 10u + limb];
+        if (l != 0ull) atomicAdd(acc + (size_t)rslot * RT_ACC_LIMBS + limb, l);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -636,18 +653,35 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     for (uint32_t v = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; v < rounded; v += (gridDim.x / RT_WF_Q) * blockDim.x) {
         const bool shade = v < n1 || (v >= r1 && v - r1 < n2);
         uint32_t want_rays = 0, want_shadows = 0, inst = 0, q = 0;
+        // everything the hit needs from the queues is asked for at once, ahead of the reservation,
+        // so that the round trips overlap
+        d3 ro = mk3(0.0, 0.0, 0.0), rd = ro, rw = ro, rc = ro;
+        uint32_t rdepth = 0, rpath = 0, rslot = 0, rflags = 0;
+        SceneHit h;
+        h.t = 0.0; h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         if (shade) {
             q = sq * a.sub + (v < n1 ? hits[v] : hits[a.sub - 1u - (v - r1)]);
             inst = a.rjobs.U(cap, JQ_INST, q);
+            ro = a.rays.ld3(cap, RQ_O, q); rd = a.rays.ld3(cap, RQ_D, q); rw = a.rays.ld3(cap, RQ_W, q); rc = a.rays.ld3(cap, RQ_C, q);
+            rdepth = a.rays.U(cap, RQ_DEPTH, q); rpath = a.rays.U(cap, RQ_PATH, q);
+            rslot = a.rays.U(cap, RQ_SLOT, q); rflags = a.rays.U(cap, RQ_FLAGS, q);
+            h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
+            h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
             const uint32_t bounds = sc.shader_bounds[sc.instances[inst].shader];
             want_rays = bounds & 0xFFFFu; want_shadows = bounds >> 16;
         }
         RT_PROF(wk, PF_TRIPS, PF_TRIP_LANES);
         RT_PROF_CYC(wk, PF_A_ITERS, t_prof);                              // hit list, instance, material bounds
-        // room in the next generation for what the hit may ask for
-        uint32_t rbase, sbase;
-        wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
+        // room in the next generation for what the hit may ask for (the answer is picked up after
+        // the hit has been taken to world space)
+        const WaveAlloc2 room = wave_alloc2_begin(a.n_out + 2 * sq, want_rays, want_shadows);
         RT_PROF_CYC(wk, PF_A_LANES, t_prof);                              // reservation
+        WorldHit wh;
+        wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
+        if (shade && !(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
+        RT_PROF_CYC(wk, PF_B_ITERS, t_prof);                              // the ray, the hit in world space
+        uint32_t rbase, sbase;
+        wave_alloc2_end(room, rbase, sbase);
         uint32_t cslot = RT_NO_SLOT;
         d3 cval = mk3(0.0, 0.0, 0.0);
         if (shade) {
@@ -655,21 +689,11 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             if (sbase + want_shadows > a.sub) { atomicAdd(a.dropped, want_shadows); want_shadows = sbase < a.sub ? a.sub - sbase : 0u; }
             QueueSink sink;
             sink.ray0 = sq * a.sub + rbase; sink.shadow0 = sq * a.sub + sbase;
-            const d3 ro = a.rays.ld3(cap, RQ_O, q), rd = a.rays.ld3(cap, RQ_D, q), rw = a.rays.ld3(cap, RQ_W, q), rc = a.rays.ld3(cap, RQ_C, q);
-            const uint32_t rdepth = a.rays.U(cap, RQ_DEPTH, q), rpath = a.rays.U(cap, RQ_PATH, q);
-            const uint32_t rslot = a.rays.U(cap, RQ_SLOT, q), rflags = a.rays.U(cap, RQ_FLAGS, q);
-            SceneHit h;
-            h.t = a.rjobs.F(cap, JQ_T, q); h.inst = inst;
-            h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
-            WorldHit wh;
-            wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
-            if (!(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
-            RT_PROF_CYC(wk, PF_B_ITERS, t_prof);                          // the ray, the hit in world space
             const DInstance& in = sc.instances[inst];
             if (rflags & 1u) { a.distance[rslot] = h.t; a.hit_id[rslot] = in.node_id; }
             sink.rays = a.out_rays; sink.shadows = a.out_shadows; sink.cap = cap;
             sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
-            sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0;
+            sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0; sink.dry = (a.debug & 4u) != 0;
             d3 local = wh.p;
             if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
             cslot = rslot;
