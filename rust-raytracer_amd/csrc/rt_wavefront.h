@@ -373,11 +373,17 @@ k_wf_walk(DScene sc, WfArgs a) {
         --sp;
         return sp < RT_WF_LDS_STACK ? lstack[sp * lstride] : gstack[sp - RT_WF_LDS_STACK];
     };
+    bool qchanged = false;                                           // a mesh took the query's answer over
     auto finish_query = [&]() {
-        const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
-        jobs.F(a.cap, JQ_T, qe) = qt; jobs.F(a.cap, JQ_CT, qe) = qct;
-        jobs.U(a.cap, JQ_INST, qe) = qinst; jobs.U(a.cap, JQ_FOUND, qe) = qfound;
-        jobs.U(a.cap, JQ_CA, qe) = qca; jobs.U(a.cap, JQ_CB, qe) = 0u;
+        if (qchanged) {                                               // (else the analytic phase's record stands)
+            const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
+            jobs.U(a.cap, JQ_FOUND, qe) = 1u;
+            if (!qshadow) {                                           // (of a shadow test only the verdict is read)
+                jobs.F(a.cap, JQ_T, qe) = qt; jobs.F(a.cap, JQ_CT, qe) = qct;
+                jobs.U(a.cap, JQ_INST, qe) = qinst;
+                jobs.U(a.cap, JQ_CA, qe) = qca; jobs.U(a.cap, JQ_CB, qe) = 0u;
+            }
+        }
         have = false;
     };
     for (;;) {
@@ -413,9 +419,9 @@ k_wf_walk(DScene sc, WfArgs a) {
                     else { qo = a.rays.ld3(a.cap, RQ_O, qe); qd = a.rays.ld3(a.cap, RQ_D, qe); }
                     const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
                     any = qshadow;
-                    qt = jobs.F(a.cap, JQ_T, qe); qct = jobs.F(a.cap, JQ_CT, qe);
-                    qinst = jobs.U(a.cap, JQ_INST, qe); qfound = jobs.U(a.cap, JQ_FOUND, qe); qca = jobs.U(a.cap, JQ_CA, qe);
-                    have = true; m = 0;
+                    qt = jobs.F(a.cap, JQ_T, qe);
+                    qinst = jobs.U(a.cap, JQ_INST, qe); qfound = jobs.U(a.cap, JQ_FOUND, qe);
+                    have = true; m = 0; qchanged = false;
                 }
             }
             if (need && have) {
@@ -492,11 +498,11 @@ k_wf_walk(DScene sc, WfArgs a) {
             if (cur == RT_WALK_DONE) {                                // this instance is done: merge, move on
                 bool settled = false;
                 if (found) {
-                    if (any) { qfound = 1u; settled = true; }
+                    if (any) { qfound = 1u; settled = true; qchanged = true; }
                     else {
                         double tw = best * inv_s;
                         if (tw < qt || (tw == qt && qfound && inst < qinst)) {
-                            qt = tw; qinst = inst; qfound = 1u;
+                            qt = tw; qinst = inst; qfound = 1u; qchanged = true;
                             qct = best; qca = tri;
                         }
                     }
