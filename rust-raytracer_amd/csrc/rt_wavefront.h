@@ -127,6 +127,23 @@ struct QueueSink {
     }
 };
 
+// Takes what QueueSink takes and only counts it: a first run of a hit's material with this sink tells
+// how many rays and shadow tests the second, real run will append, so that exactly that much room
+// is reserved and the queues stay free of holes.
+struct CountSink {
+    uint32_t nrays, nshadows, depth;
+    bool drop_dead;
+    RT_DEV bool room() const { return true; }
+    RT_DEV uint32_t mark() const { return nrays | (nshadows << 16); }
+    RT_DEV void ray(d3, d3, d3, d3 c, uint32_t) {
+        if (drop_dead && !(depth > 0 && (c.x + c.y + c.z) > RT_MIN_CONTRIBUTION)) return;
+        nrays++;
+    }
+    RT_DEV void shadow(d3, d3, double, d3) { nshadows++; }
+    template <class K>
+    RT_DEV void scale(uint32_t, uint32_t, K) {}
+};
+
 template <bool COUNT>
 RT_DEV void wf_flush(DCounters* g, const Work<COUNT>& wk, unsigned long long cam, uint32_t mode) {
     if (!COUNT) return;
@@ -678,16 +695,23 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
         }
         RT_PROF(wk, PF_TRIPS, PF_TRIP_LANES);
         RT_PROF_CYC(wk, PF_A_ITERS, t_prof);                              // hit list, instance, material bounds
-        // room in the next generation for what the hit may ask for (the answer is picked up after
-        // the hit has been taken to world space)
-        const WaveAlloc2 room = wave_alloc2_begin(a.n_out + 2 * sq, want_rays, want_shadows);
-        RT_PROF_CYC(wk, PF_A_LANES, t_prof);                              // reservation
         WorldHit wh;
         wh.p = ro; wh.n = rd; wh.tangent = rd; wh.u = 0.0; wh.v = 0.0; wh.inst = inst;
         if (shade && !(a.debug & 1u)) world_hit<F, COUNT>(sc, ro, rd, h, wh, wk);
         RT_PROF_CYC(wk, PF_B_ITERS, t_prof);                              // the ray, the hit in world space
+        // A material that spawns rays is run twice: first only to count what it will append (how
+        // many rays depends on the hit: total reflection, contributions below the threshold), ...
+        if (shade && want_rays && !(a.debug & 3u)) {
+            CountSink cs;
+            cs.nrays = 0; cs.nshadows = 0; cs.depth = rdepth - 1; cs.drop_dead = sc.has_background == 0;
+            Work<false> nowk = {};
+            (void)shade_hit<F, false>(sc, sc.instances[inst].shader, wh, rd, rc, 0ull, rpath, cs, nowk);
+            want_rays = min(want_rays, cs.nrays); want_shadows = min(want_shadows, cs.nshadows);
+        }
+        // ... then, with exactly that much room reserved in the next generation, for real
         uint32_t rbase, sbase;
-        wave_alloc2_end(room, rbase, sbase);
+        wave_alloc2(a.n_out + 2 * sq, want_rays, want_shadows, rbase, sbase);
+        RT_PROF_CYC(wk, PF_A_LANES, t_prof);                              // counting run, reservation
         uint32_t cslot = RT_NO_SLOT;
         d3 cval = mk3(0.0, 0.0, 0.0);
         if (shade) {
