@@ -236,7 +236,7 @@ int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, 
     // which: 0 analytic, 1 shade, 2 settle
     const bool hot = ds.hot_bytes > 0;                                 // the scene's small tables fit into LDS
     const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
-    uint32_t lds = tables + 512u + 32u;                                // + the dealt-out list, wave counts
+    uint32_t lds = tables;
     if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
     if (which == 2) lds = 4u * 640u * 8u;
     const void* fn;

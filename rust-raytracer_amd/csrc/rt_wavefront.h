@@ -4,14 +4,16 @@
 // frame are processed generation by generation (camera rays, then everything they spawned, ...)
 // and every generation runs through four launches
 //     k_wf_analytic   one thread per query (ray or shadow test): gate of Scene::cast_ray, every
-//                     primitive except the un-wrapped meshes; queries that still need the
-//                     meshes go onto the walk list
+//                     primitive except the un-wrapped meshes; queries whose ray reaches a mesh's
+//                     bounding box go onto the walk list
 //     k_wf_walk       persistent lanes take queries off the walk list and walk the mesh BVHs
 //                     (LDS-resident), replacing a finished query at once
-//     k_wf_shade      one thread per query: hit -> world space, shader tree, new rays and
-//                     shadow tests appended to the next generation's queues
-//     k_wf_accumulate the colour contributions of the generation into the per-sample
-//                     fixed-point accumulators
+//     k_wf_settle     one thread per query: the colour terms of shadow tests that nothing blocks
+//                     and of rays that left the scene go to the accumulators; hits are listed
+//     k_wf_shade      one thread per listed hit: hit -> world space, shader tree, new rays and
+//                     shadow tests appended to the next generation's queues, the hit's own
+//                     colour term to the accumulators
+// (sky-box scenes add k_wf_accumulate for the background seen by rays that failed the gate).
 // Every lane of every kernel has a query of the same kind to work on, each kernel only holds
 // the registers its phase needs (more waves per SIMD to hide the queue traffic), and the walk
 // draws on millions of queries so that one long walk no longer holds up a wave.
@@ -198,69 +200,28 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ dealing work out within a workgroup
-// The 256 threads of a workgroup each hold an item of kind 0 (nothing to do), 1 or 2.  Afterwards
-// list[0 .. tot1) names the threads with kind-1 items and list[256 - tot2 .. 256) those with kind-2
-// items, both in thread order, so that thread t can take over the item of thread list[t]: threads
-// with work sit side by side, the two kinds in different waves as far as they fit, and waves left
-// without work can skip it.  `list` (256 x u16) and `wcount` (4 x 2 words) are LDS.  Two barriers:
-// every thread of the workgroup must call, and a caller may write neither array before all its
-// threads have read `list` (the next call's writes to `list` come after its first barrier).
-RT_DEV void wg_deal(uint32_t kind, uint16_t* list, uint32_t* wcount, uint32_t& tot1, uint32_t& tot2) {
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned long long b1 = __ballot(kind == 1u), b2 = __ballot(kind == 2u);
-    if (lane == 0u) { wcount[2 * wave] = __popcll(b1); wcount[2 * wave + 1] = __popcll(b2); }
-    __syncthreads();
-    uint32_t before1 = 0, before2 = 0;
-    tot1 = 0; tot2 = 0;
-    for (uint32_t w = 0; w < 4u; ++w) {
-        const uint32_t c1 = wcount[2 * w], c2 = wcount[2 * w + 1];
-        if (w < wave) { before1 += c1; before2 += c2; }
-        tot1 += c1; tot2 += c2;
-    }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (kind == 1u) list[before1 + __popcll(b1 & below)] = (uint16_t)threadIdx.x;
-    if (kind == 2u) list[255u - (before2 + __popcll(b2 & below))] = (uint16_t)threadIdx.x;
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------ analytic phase
-// A workgroup takes 256 queue entries at a time; the entries that hold a query (the others are
-// holes left by the shading phase) are dealt out again (wg_deal): rays from thread 0 upwards,
-// shadow tests from thread 255 downwards.
-// LDS: [small scene tables][256 x u16 list][4 x 2 wave counts]
+// One thread per queue entry: the sub-queue's rays first, then its shadow tests.
+// LDS: [small scene tables]
 template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
-    uint16_t* list = reinterpret_cast<uint16_t*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u));
-    uint32_t* wcount = reinterpret_cast<uint32_t*>(list + 256);
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
-    // whole workgroups stay in the loop: it holds barriers
-    for (uint32_t w0 = (blockIdx.x / RT_WF_Q) * 256u; w0 < nr + nsh; w0 += (gridDim.x / RT_WF_Q) * 256u) {
-        uint32_t kind = 0;
-        {
-            const uint32_t ql = w0 + threadIdx.x;
-            if (ql < nr) {
-                const uint32_t q = sq * a.sub + ql;
-                if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
-                if (a.rays.U(cap, RQ_FLAGS, q) & 8u) a.rjobs.U(cap, JQ_FLAGS, q) = 6u;        // a hole
-                else kind = 1u;
-            } else if (ql < nr + nsh) {
-                const uint32_t q = sq * a.sub + ql - nr;
-                if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) a.sjobs.U(cap, JQ_FLAGS, q) = 7u;   // a hole
-                else kind = 2u;
-            }
+    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
+        if (ql < nr) {
+            const uint32_t q = sq * a.sub + ql;
+            if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
+            if (a.rays.U(cap, RQ_FLAGS, q) & 8u) { a.rjobs.U(cap, JQ_FLAGS, q) = 6u; continue; }        // a hole (queue overflow only)
+        } else {
+            const uint32_t q = sq * a.sub + ql - nr;
+            if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { a.sjobs.U(cap, JQ_FLAGS, q) = 7u; continue; }   // a hole
         }
-        uint32_t tot1, tot2;
-        wg_deal(kind, list, wcount, tot1, tot2);
-        if (!(threadIdx.x < tot1 || threadIdx.x >= 256u - tot2)) continue;
-        const uint32_t ql = w0 + list[threadIdx.x];
         const bool shadow = ql >= nr;
         const uint32_t q = sq * a.sub + (shadow ? ql - nr : ql);      // entry of the shadow-test / ray arrays
         const WfQueue& jobs = shadow ? a.sjobs : a.rjobs;
@@ -654,10 +615,11 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
 }
 
 // k_wf_shade: one thread per hit.  A hit's new rays and shadow tests are written straight into the
-// next generation's queues.  Room for the most its material can ask for is reserved first (one
-// atomic per wave); entries the hit did not use after all are marked as holes (ray flags bit 3 /
-// shadow slot RT_NO_SLOT) and cost the next generation one skipped thread each.  The hit's own
-// colour term goes to the accumulators at once.
+// next generation's queues, into room reserved beforehand (one atomic per wave): what the
+// material's structure says for materials without rays, what a counting run of the material says
+// for the others.  Only when a sub-queue is full do reserved entries stay unused; those are marked
+// as holes (ray flags bit 3 / shadow slot RT_NO_SLOT).  The hit's own colour term goes to the
+// accumulators at once.
 // LDS: [small scene tables][per wave 64 x 10 words of staging]
 template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
