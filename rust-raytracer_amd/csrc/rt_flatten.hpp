@@ -144,7 +144,7 @@ struct FlatScene {
     bool lds_exact = true;           // every mesh coordinate is an f32 value, so the f32 vertex copies lose nothing
 };
 
-// ---- BVH build: binned SAH, leaves of <= 4 triangles ----
+// ---- BVH build: binned SAH, leaves of <= 2 triangles (measured: 4 costs 2 % more, 1 costs 18 % more on the north-star scene) ----
 struct BuildTri { V3 lo, hi, c; uint32_t face; };
 struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
@@ -159,7 +159,7 @@ inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes
         chi = {std::max(chi.x, t.c.x), std::max(chi.y, t.c.y), std::max(chi.z, t.c.z)};
     }
     nodes[node_idx].lo = lo; nodes[node_idx].hi = hi;
-    const uint32_t LEAF = 4;
+    const uint32_t LEAF = 2;
     if (count <= LEAF || depth >= RT_BVH_STACK - 2) { nodes[node_idx].first = first; nodes[node_idx].count = count; return; }
     auto area = [](V3 a, V3 b) { V3 d = b - a; return 2.0 * (d.x * d.y + d.y * d.z + d.z * d.x); };
     const int BINS = 16;
