@@ -145,9 +145,9 @@ def main():
             stage_ms[k] /= args.steps
         # dominant kernel of rank 0's share
         if stage_ms["aa"] >= stage_ms["pass1"]:
-            kernel, k_ms, k_flops = "AA-resolve pass (k_wf_analytic + k_wf_walk + k_wf_shade + k_wf_accumulate per generation)", stage_ms["aa"], flops_aa
+            kernel, k_ms, k_flops = "AA-resolve pass (k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation)", stage_ms["aa"], flops_aa
         else:
-            kernel, k_ms, k_flops = "pass 1 (k_wf_analytic + k_wf_walk + k_wf_shade + k_wf_accumulate per generation)", stage_ms["pass1"], flops_pass1
+            kernel, k_ms, k_flops = "pass 1 (k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation)", stage_ms["pass1"], flops_pass1
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         fb_bytes = WIDTH * HEIGHT * (32 + 3)   # f64 colour+distance written once, RGB8 written once
         out = {
