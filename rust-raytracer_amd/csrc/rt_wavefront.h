@@ -308,20 +308,26 @@ k_wf_walk(DScene sc, WfArgs a) {
         }
         if (threadIdx.x == 0) starts[RT_WF_Q] = run;
     }
+    __syncthreads();
+    // A short list is walked by few workgroups, in small portions: the others leave before they
+    // copy the BVH (late generations and small frames hold a few thousand queries; every wave
+    // still gets a portion while there are fewer portions than waves).
+    const uint32_t total = starts[RT_WF_Q];
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t chunk = min(256u, max(64u, (total / waves + 63u) & ~63u));
+    if (blockIdx.x * 4u * chunk >= total) return;                    // one portion per SIMD of a staying workgroup (also: nothing to walk at all)
     if constexpr (LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);
         uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(blob));
         for (uint32_t i = threadIdx.x; i < sc.lds_blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
-    if (starts[RT_WF_Q] == 0) return;
     const uint32_t nm = sc.num_mesh_instances;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* gstack = a.walk_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (RT_BVH_STACK - RT_WF_LDS_STACK);
     Work<COUNT> wk = {};
     // The RT_WF_Q walk lists are read as one: `starts` holds where each begins in the joint numbering.
-    const uint32_t total = starts[RT_WF_Q];
     uint32_t chunk_next = 0, chunk_end = 0;                          // the wave's reserved part of the joint list
     bool dry = total == 0;                                           // wave-uniform: the joint list is used up
     bool have = false, walking = false;
@@ -374,13 +380,13 @@ k_wf_walk(DScene sc, WfArgs a) {
             const unsigned long long jm = __ballot(want);
             if (jm) {
                 const uint32_t nwant = (uint32_t)__popcll(jm), rank = (uint32_t)__popcll(jm & lt);
-                // (wave-uniform) a used-up chunk -> reserve the next 256 entries of the joint list
+                // (wave-uniform) a used-up chunk -> reserve the next portion of the joint list
                 if (chunk_next >= chunk_end || chunk_next >= total) {
                     uint32_t base = 0;
                     const uint32_t leader = (uint32_t)(__ffsll((long long)jm) - 1);
-                    if (lane == leader) base = atomicAdd(a.walk_next, 256u);
+                    if (lane == leader) base = atomicAdd(a.walk_next, chunk);
                     base = __shfl(base, leader);
-                    chunk_next = base; chunk_end = base + 256u;
+                    chunk_next = base; chunk_end = base + chunk;
                     if (base >= total) dry = true;
                 }
                 const uint32_t avail = dry ? 0u : min(chunk_end, total) - chunk_next;
