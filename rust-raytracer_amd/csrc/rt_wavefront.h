@@ -352,10 +352,15 @@ k_wf_walk(DScene sc, WfArgs a) {
         else if (sp < RT_BVH_STACK) gstack[sp - RT_WF_LDS_STACK] = v;
         ++sp;
     };
+    // (the LDS part of the stack through a pointer that says so: otherwise the compiler merges the
+    // two reads of pop into one generic-pointer load, which is slower and waits on both memory counters)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const lstack3 = (lds_u32*)lstack;
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return RT_WALK_DONE;
         --sp;
-        return sp < RT_WF_LDS_STACK ? lstack[sp * lstride] : gstack[sp - RT_WF_LDS_STACK];
+        if (sp < RT_WF_LDS_STACK) return lstack3[sp * lstride];
+        return gstack[sp - RT_WF_LDS_STACK];
     };
     bool qchanged = false;                                           // a mesh took the query's answer over
     auto finish_query = [&]() {
