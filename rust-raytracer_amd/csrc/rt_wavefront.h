@@ -206,10 +206,11 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
-    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
+    if ((blockIdx.x / RT_WF_Q) * blockDim.x >= nr + nsh) return;     // nothing for this workgroup: leave before the tables are copied
+    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
@@ -635,13 +636,14 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
 template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
-    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u)) + (threadIdx.x >> 6) * 640u;
     const uint32_t sq = blockIdx.x % RT_WF_Q;
     const uint32_t cap = a.cap;
     const uint32_t n1 = min(a.hit_count[2 * sq], a.sub), n2 = min(a.hit_count[2 * sq + 1], a.sub - n1);
     const uint32_t r1 = (n1 + 63u) & ~63u;                            // the second kind starts in a wave of its own
     const uint32_t rounded = (r1 + n2 + 63u) & ~63u;
+    if ((blockIdx.x / RT_WF_Q) * blockDim.x >= rounded) return;      // nothing for this workgroup: leave before the tables are copied
+    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u)) + (threadIdx.x >> 6) * 640u;
     const uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
     long long t_prof = COUNT ? clock64() : 0;
