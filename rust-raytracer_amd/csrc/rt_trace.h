@@ -300,6 +300,20 @@ RT_DEV bool slab_f32(const float* lo, const float* hi, d3 o, d3 inv, double tmax
     tnear = tn;
     return tn <= tf && tf >= 0.0 && tn <= tmax;
 }
+// LDS copies of a node / a triangle, read 16 bytes at a time (the blob and the records' offsets in
+// it are multiples of 16 bytes; left to itself the compiler reads them word by word).
+RT_DEV LBvhNode lds_node(const LBvhNode* p) {
+    const uint4* w = reinterpret_cast<const uint4*>(p);
+    union { uint4 w[4]; LBvhNode n; } u;
+    u.w[0] = w[0]; u.w[1] = w[1]; u.w[2] = w[2]; u.w[3] = w[3];
+    return u.n;
+}
+RT_DEV LMeshTri lds_tri(const LMeshTri* p) {
+    const uint4* w = reinterpret_cast<const uint4*>(p);
+    union { uint4 w[4]; LMeshTri t; } u;
+    u.w[0] = w[0]; u.w[1] = w[1]; u.w[2] = w[2]; u.w[3] = w[3];
+    return u.t;
+}
 // Mesh::check_triangle (mesh.rs:416-443) on either triangle record
 template <class TRI>
 RT_DEV bool mesh_tri_test(const TRI& tr, const LRay& r, double& t) {
@@ -353,7 +367,7 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
             if (LDS) {
-                const LBvhNode& n = lnodes[cur];
+                const LBvhNode n = lds_node(lnodes + cur);
                 h0 = slab_f32(n.lo[0], n.hi[0], r.o, inv, best, tn0);
                 h1 = slab_f32(n.lo[1], n.hi[1], r.o, inv, best, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
@@ -376,7 +390,7 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
         for (uint32_t i = 0; i < cnt; ++i) {                     // the leaf's triangles
             double t;
             RT_COUNT(wk, tri_tests);
-            bool hit = LDS ? mesh_tri_test(ltris[base + i], r, t) : mesh_tri_test(gtris[base + i], r, t);
+            bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), r, t) : mesh_tri_test(gtris[base + i], r, t);
             if (hit) {
                 if (any) {
                     if (inclusive ? t <= tmax : t < tmax) { found = true; }
@@ -510,7 +524,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
             if (COUNT) wk.box_tests += 2;
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
-                const LBvhNode& n = lnodes[cur];
+                const LBvhNode n = lds_node(lnodes + cur);
                 h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
                 h1 = slab_f32(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
@@ -535,7 +549,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
                     RT_COUNT(wk, tri_tests);
-                    bool hit = LDS ? mesh_tri_test(ltris[base + i], lr, t) : mesh_tri_test(gtris[base + i], lr, t);
+                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, t) : mesh_tri_test(gtris[base + i], lr, t);
                     if (hit) {
                         if (any) {
                             if (inclusive ? t <= tmax : t < tmax) found = true;

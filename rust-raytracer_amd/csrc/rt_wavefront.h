@@ -449,17 +449,10 @@ k_wf_walk(DScene sc, WfArgs a) {
             if (COUNT) wk.box_tests += 2;
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
-                // (the blob and the records' offsets in it are multiples of 16 bytes: a record is four 16-byte LDS reads)
-                const uint4* np = reinterpret_cast<const uint4*>(lnodes + cur);
-                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-                LBvhNode n;
-                n.lo[0][0] = __uint_as_float(w0.x); n.lo[0][1] = __uint_as_float(w0.y); n.lo[0][2] = __uint_as_float(w0.z);
-                n.lo[1][0] = __uint_as_float(w0.w); n.lo[1][1] = __uint_as_float(w1.x); n.lo[1][2] = __uint_as_float(w1.y);
-                n.hi[0][0] = __uint_as_float(w1.z); n.hi[0][1] = __uint_as_float(w1.w); n.hi[0][2] = __uint_as_float(w2.x);
-                n.hi[1][0] = __uint_as_float(w2.y); n.hi[1][1] = __uint_as_float(w2.z); n.hi[1][2] = __uint_as_float(w2.w);
+                const LBvhNode n = lds_node(lnodes + cur);
                 h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
                 h1 = slab_f32(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
-                c0 = w3.x; c1 = w3.y;
+                c0 = n.child[0]; c1 = n.child[1];
             } else {
                 const DBvhNode& n = gnodes[cur];
                 h0 = slab(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
@@ -481,15 +474,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
                     RT_COUNT(wk, tri_tests);
-                    bool hit;
-                    if (LDS) {
-                        const uint4* tp = reinterpret_cast<const uint4*>(ltris + base + i);
-                        union { uint4 w[4]; LMeshTri tr; } u;
-                        u.w[0] = tp[0]; u.w[1] = tp[1]; u.w[2] = tp[2]; u.w[3] = tp[3];
-                        hit = mesh_tri_test(u.tr, lr, t);
-                    } else {
-                        hit = mesh_tri_test(gtris[base + i], lr, t);
-                    }
+                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, t) : mesh_tri_test(gtris[base + i], lr, t);
                     if (hit) {
                         if (any) {
                             if (inclusive ? t <= tmax : t < tmax) found = true;
