@@ -253,11 +253,14 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         bool found = trace_scene<F, COUNT, HAS_MESH>(sc, o, d, shadow, max_distance, h, wk);
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
-        jobs.F(cap, JQ_T, q) = shadow ? max_distance : h.t;
-        jobs.F(cap, JQ_CT, q) = h.c.t;
-        jobs.U(cap, JQ_INST, q) = h.inst; jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
-        jobs.U(cap, JQ_CA, q) = h.c.a; jobs.U(cap, JQ_CB, q) = h.c.b;
+        jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
         jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
+        if (!shadow) {                                                // (of a shadow test only the verdict is kept)
+            jobs.F(cap, JQ_T, q) = h.t;
+            jobs.F(cap, JQ_CT, q) = h.c.t;
+            jobs.U(cap, JQ_INST, q) = h.inst;
+            jobs.U(cap, JQ_CA, q) = h.c.a; jobs.U(cap, JQ_CB, q) = h.c.b;
+        }
         if constexpr (HAS_MESH) {
             // Only queries whose ray reaches the bounding box of some mesh go on to the walk (the walk
             // makes the same test, with the same numbers, first thing for every instance).
@@ -405,12 +408,15 @@ k_wf_walk(DScene sc, WfArgs a) {
                     const uint32_t e = a.walk_list[(size_t)lo * (2u * a.sub) + (idx - starts[lo])];
                     qshadow = (e & 0x80000000u) != 0;
                     qe = e & 0x7FFFFFFFu;
-                    if (qshadow) { qo = a.shadows.ld3(a.cap, SQ_O, qe); qd = a.shadows.ld3(a.cap, SQ_D, qe); }
-                    else { qo = a.rays.ld3(a.cap, RQ_O, qe); qd = a.rays.ld3(a.cap, RQ_D, qe); }
-                    const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
+                    if (qshadow) {                                    // (a shadow test on this list has found nothing yet)
+                        qo = a.shadows.ld3(a.cap, SQ_O, qe); qd = a.shadows.ld3(a.cap, SQ_D, qe);
+                        qt = a.shadows.F(a.cap, SQ_DIST, qe); qinst = 0; qfound = 0;
+                    } else {
+                        qo = a.rays.ld3(a.cap, RQ_O, qe); qd = a.rays.ld3(a.cap, RQ_D, qe);
+                        qt = a.rjobs.F(a.cap, JQ_T, qe);
+                        qinst = a.rjobs.U(a.cap, JQ_INST, qe); qfound = a.rjobs.U(a.cap, JQ_FOUND, qe);
+                    }
                     any = qshadow;
-                    qt = jobs.F(a.cap, JQ_T, qe);
-                    qinst = jobs.U(a.cap, JQ_INST, qe); qfound = jobs.U(a.cap, JQ_FOUND, qe);
                     have = true; m = 0; qchanged = false;
                 }
             }
