@@ -79,6 +79,9 @@ struct RtScene {
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    // queue pipeline as several chains side by side: chain 0 runs on the caller's stream, the others on these
+    hipStream_t chain_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t chain_fork = nullptr, chain_join[3] = {nullptr, nullptr, nullptr};
 };
 
 extern "C" {
@@ -105,6 +108,9 @@ void rt_scene_destroy(RtScene* s) {
                          &s->wf_rays[0], &s->wf_rays[1], &s->wf_shadows[0], &s->wf_shadows[1], &s->wf_rjobs, &s->wf_sjobs, &s->wf_contrib,
                          &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->chain_join) if (e) (void)hipEventDestroy(e);
+    if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
+    for (auto& st : s->chain_stream) if (st) (void)hipStreamDestroy(st);
     if (s->h_dropped) (void)hipHostFree(s->h_dropped);
     delete s;
 }
@@ -179,6 +185,11 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     }
     for (auto& e : s->ev)
         if (hipEventCreate(&e) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    for (auto& st : s->chain_stream)
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipStreamCreate failed"); }
+    for (auto& e : s->chain_join)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
     if (hipHostMalloc((void**)&s->h_dropped, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipHostMalloc failed"); }
     *s->h_dropped = 0;
     *out = s;
@@ -261,7 +272,7 @@ int wf_launch(int which, uint32_t features, bool count, uint32_t grid, hipStream
     if (covers(V_CSG)) return wf_launch_variant<V_CSG>(which, count, grid, stream, ds, rp, wa);
     return wf_launch_variant<V_NO_INLINE>(which, count, grid, stream, ds, rp, wa);
 }
-int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {
+int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {   // num_cus: the chain's share of the CUs
     const bool lds_bvh = ds.lds_blob_bytes != 0;
     const uint32_t block = lds_bvh ? 1024u : 256u, grid = lds_bvh ? num_cus : num_cus * 8u;
     const uint32_t lds = block * RT_WF_LDS_STACK * 4u + 2048u + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
@@ -320,6 +331,15 @@ uint32_t refill_min() {
 uint32_t descend_frac() {
     static const uint32_t b = [] { const char* e = std::getenv("RT_DESCEND_FRAC"); long v = e ? std::atol(e) : 2; return (uint32_t)std::max<long>(0, std::min<long>(v, 8)); }();
     return b;
+}
+// Chains of the queue pipeline (1, 2 or 4): the sub-queues are split among them and each runs its
+// generations on a stream of its own, so that one chain's launch tails (the last long BVH walks,
+// the latency of small launches) are filled by the others.
+uint32_t wf_chains(size_t pixels) {
+    const char* e = std::getenv("RT_WF_CHAINS");                       // (read per frame: the tests switch it)
+    const long forced = e ? std::atol(e) : 0L;
+    if (forced > 0) return forced >= 4 ? 4u : (forced >= 2 ? 2u : 1u);
+    return pixels >= (1u << 20) ? 2u : 4u;                            // measured: 1080p frame 58.7 / 54.9 / 55.8 ms with 1 / 2 / 4 chains, an eighth of it 15.0 / 13.6 / 13.2 ms
 }
 uint32_t trace_rounds(uint32_t recursion_depth) {
     static const long forced = [] { const char* e = std::getenv("RT_TRACE_ROUNDS"); return e ? std::atol(e) : 0L; }();
@@ -507,25 +527,44 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wa.out_rays = queue(s->wf_rays[0], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
         hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
         HIP_TRY(hipGetLastError());
+        const uint32_t chains = wf_chains((size_t)W * num_rows);
+        uint32_t* const overflow0 = wa.walk_overflow;
+        if (chains > 1) {                                             // the other chains start once generation 0 is in the queues
+            HIP_TRY(hipEventRecord(s->chain_fork, stream));
+            for (uint32_t c = 1; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(s->chain_stream[c - 1], s->chain_fork, 0));
+        }
         for (uint32_t g = 0; g < generations; ++g) {
             wa.rays = queue(s->wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(s->wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
             wa.out_rays = queue(s->wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
-            wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g; wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g;
+            wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g;
             wa.hit_count = (unsigned int*)s->wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
-            int lrc = wf_launch(0, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
-            if (lrc != RT_OK) return lrc;
-            if (s->ds.features & RTF_MESH) {
-                lrc = wf_launch_walk(count_work, (uint32_t)s->num_cus, stream, s->ds, wa);
+            for (uint32_t c = 0; c < chains; ++c) {
+                hipStream_t cs = c == 0 ? stream : s->chain_stream[c - 1];
+                const uint32_t cus = std::max(1u, (uint32_t)s->num_cus / chains);
+                wa.sq_count = RT_WF_Q / chains; wa.sq_base = c * wa.sq_count;
+                wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g + c;   // (a cursor per chain)
+                wa.walk_overflow = overflow0 + (size_t)c * cus * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK);   // (a walk launch has at most 2048 threads per CU)
+                const uint32_t cgrid = grid / chains;
+                int lrc = wf_launch(0, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
+                if (s->ds.features & RTF_MESH) {
+                    lrc = wf_launch_walk(count_work, cus, cs, s->ds, wa);
+                    if (lrc != RT_OK) return lrc;
+                }
+                lrc = wf_launch(2, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                if (lrc != RT_OK) return lrc;
+                lrc = wf_launch(1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                if (lrc != RT_OK) return lrc;
+                if (s->ds.has_background) {
+                    hipLaunchKernelGGL(k_wf_accumulate, dim3(cgrid), dim3(256), 0, cs, wa);
+                    HIP_TRY(hipGetLastError());
+                }
             }
-            lrc = wf_launch(2, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
-            if (lrc != RT_OK) return lrc;
-            lrc = wf_launch(1, s->ds.features, count_work, grid, stream, s->ds, rp, wa);
-            if (lrc != RT_OK) return lrc;
-            if (s->ds.has_background) {
-                hipLaunchKernelGGL(k_wf_accumulate, dim3(grid), dim3(256), 0, stream, wa);
-                HIP_TRY(hipGetLastError());
-            }
+        }
+        wa.walk_overflow = overflow0;
+        for (uint32_t c = 1; c < chains; ++c) {                       // the frame goes on when every chain is through
+            HIP_TRY(hipEventRecord(s->chain_join[c - 1], s->chain_stream[c - 1]));
+            HIP_TRY(hipStreamWaitEvent(stream, s->chain_join[c - 1], 0));
         }
         if (mode == 0)
             hipLaunchKernelGGL(k_acc_resolve, dim3(2048), dim3(256), 0, stream, wa.acc, wa.acc_flags, (const unsigned int*)nullptr, 0u, (uint32_t)npix, dst);

@@ -57,6 +57,10 @@ struct WfArgs {
     const unsigned int* n_in;
     uint32_t sub;                     // capacity of one sub-queue
     uint32_t cap;                     // RT_WF_Q * sub: entries per array
+    // The sub-queues are independent of each other from generation 0 on, so a frame may be run as
+    // several chains of launches side by side (one HIP stream each), every chain with a range of
+    // sub-queues of its own: this launch works on sub-queues [sq_base, sq_base + sq_count).
+    uint32_t sq_base, sq_count;
     // the next generation
     WfQueue out_rays, out_shadows;
     unsigned int* n_out;
@@ -207,14 +211,14 @@ template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
-    const uint32_t sq = blockIdx.x % RT_WF_Q;
+    const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
-    if ((blockIdx.x / RT_WF_Q) * blockDim.x >= nr + nsh) return;     // nothing for this workgroup: leave before the tables are copied
+    if ((blockIdx.x / a.sq_count) * blockDim.x >= nr + nsh) return;     // nothing for this workgroup: leave before the tables are copied
     const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
-    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
+    for (uint32_t ql = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / a.sq_count) * blockDim.x) {
         if (ql < nr) {
             const uint32_t q = sq * a.sub + ql;
             if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
@@ -303,20 +307,20 @@ k_wf_walk(DScene sc, WfArgs a) {
     const uint8_t* blob = rt_lds_dynamic + (size_t)blockDim.x * RT_WF_LDS_STACK * 4u + 2048u;
     if (threadIdx.x < 64) {                                          // exclusive scan of the list lengths by the first wave
         uint32_t run = 0;
-        for (uint32_t base = 0; base < RT_WF_Q; base += 64) {
-            uint32_t n = min(a.walk_count[base + threadIdx.x], 2u * a.sub);
+        for (uint32_t base = 0; base < a.sq_count; base += 64) {
+            uint32_t n = base + threadIdx.x < a.sq_count ? min(a.walk_count[a.sq_base + base + threadIdx.x], 2u * a.sub) : 0u;
             uint32_t incl = n;
             for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
             starts[base + threadIdx.x] = run + incl - n;
             run += __shfl(incl, 63);
         }
-        if (threadIdx.x == 0) starts[RT_WF_Q] = run;
+        if (threadIdx.x == 0) starts[a.sq_count] = run;
     }
     __syncthreads();
     // A short list is walked by few workgroups, in small portions: the others leave before they
     // copy the BVH (late generations and small frames hold a few thousand queries; every wave
     // still gets a portion while there are fewer portions than waves).
-    const uint32_t total = starts[RT_WF_Q];
+    const uint32_t total = starts[a.sq_count];
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t chunk = min(256u, max(64u, (total / waves + 63u) & ~63u));
     if (blockIdx.x * 4u * chunk >= total) return;                    // one portion per SIMD of a staying workgroup (also: nothing to walk at all)
@@ -331,7 +335,7 @@ k_wf_walk(DScene sc, WfArgs a) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* gstack = a.walk_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (RT_BVH_STACK - RT_WF_LDS_STACK);
     Work<COUNT> wk = {};
-    // The RT_WF_Q walk lists are read as one: `starts` holds where each begins in the joint numbering.
+    // The chain's walk lists are read as one: `starts` holds where each begins in the joint numbering.
     uint32_t chunk_next = 0, chunk_end = 0;                          // the wave's reserved part of the joint list
     bool dry = total == 0;                                           // wave-uniform: the joint list is used up
     bool have = false, walking = false;
@@ -403,9 +407,9 @@ k_wf_walk(DScene sc, WfArgs a) {
                 chunk_next += min(nwant, avail);
                 if (want && rank < avail) {
                     // which list does joint entry idx belong to?  (largest l with starts[l] <= idx)
-                    uint32_t lo = 0, hi = RT_WF_Q;
+                    uint32_t lo = 0, hi = a.sq_count;
                     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= idx) lo = mid; else hi = mid; }
-                    const uint32_t e = a.walk_list[(size_t)lo * (2u * a.sub) + (idx - starts[lo])];
+                    const uint32_t e = a.walk_list[(size_t)(a.sq_base + lo) * (2u * a.sub) + (idx - starts[lo])];
                     qshadow = (e & 0x80000000u) != 0;
                     qe = e & 0x7FFFFFFFu;
                     if (qshadow) {                                    // (a shadow test on this list has found nothing yet)
@@ -593,14 +597,14 @@ template <uint32_t F, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
     unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic) + (threadIdx.x >> 6) * 640u;
-    const uint32_t sq = blockIdx.x % RT_WF_Q;
+    const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
     const uint32_t cap = a.cap;
     const uint32_t nq = nr + nsh;
     const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: reservation and accumulation are wave operations
     uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
-    for (uint32_t ql = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / RT_WF_Q) * blockDim.x) {
+    for (uint32_t ql = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / a.sq_count) * blockDim.x) {
         const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
         uint32_t kind = 0;
         uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
@@ -642,19 +646,19 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
 template <uint32_t F, bool COUNT, bool HOT>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
-    const uint32_t sq = blockIdx.x % RT_WF_Q;
+    const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t cap = a.cap;
     const uint32_t n1 = min(a.hit_count[2 * sq], a.sub), n2 = min(a.hit_count[2 * sq + 1], a.sub - n1);
     const uint32_t r1 = (n1 + 63u) & ~63u;                            // the second kind starts in a wave of its own
     const uint32_t rounded = (r1 + n2 + 63u) & ~63u;
-    if ((blockIdx.x / RT_WF_Q) * blockDim.x >= rounded) return;      // nothing for this workgroup: leave before the tables are copied
+    if ((blockIdx.x / a.sq_count) * blockDim.x >= rounded) return;      // nothing for this workgroup: leave before the tables are copied
     const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     unsigned long long* stage = reinterpret_cast<unsigned long long*>(rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u)) + (threadIdx.x >> 6) * 640u;
     const uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
     long long t_prof = COUNT ? clock64() : 0;
     RT_PROF_CYC(wk, PF_CYC_FETCH, t_prof);                            // (start-up: the scene tables into LDS)
-    for (uint32_t v = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; v < rounded; v += (gridDim.x / RT_WF_Q) * blockDim.x) {
+    for (uint32_t v = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; v < rounded; v += (gridDim.x / a.sq_count) * blockDim.x) {
         const bool shade = v < n1 || (v >= r1 && v - r1 < n2);
         uint32_t want_rays = 0, want_shadows = 0, inst = 0, q = 0;
         // everything the hit needs from the queues is asked for at once, ahead of the reservation,
@@ -725,10 +729,10 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
 // One thread per (ray, limb): the nine limbs of one sample are adjacent words.
 __global__ void __launch_bounds__(256)
 k_wf_accumulate(WfArgs a) {
-    const uint32_t sq = blockIdx.x % RT_WF_Q;
+    const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub);
     const uint32_t tasks = nr * RT_ACC_LIMBS;
-    for (uint32_t t = (blockIdx.x / RT_WF_Q) * blockDim.x + threadIdx.x; t < tasks; t += (gridDim.x / RT_WF_Q) * blockDim.x) {
+    for (uint32_t t = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; t < tasks; t += (gridDim.x / a.sq_count) * blockDim.x) {
         const uint32_t ql = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
         const uint32_t e = sq * a.sub + ql;
         const uint32_t slot = a.contrib.U(a.cap, CQ_SLOT, e);

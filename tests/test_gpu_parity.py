@@ -227,6 +227,24 @@ def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatc
     assert a["counters"]["stack_overflows"] == 0
 
 
+@pytest.mark.parametrize("name,width", [("glass_monkey", 320), ("many_balls", 160)])
+def test_chain_count_does_not_change_the_frame(name, width, device_scene, scene_cache, monkeypatch):
+    """The queue pipeline run as 1, 2 or 4 chains of launches on separate streams: the same frame."""
+    s = scene_cache(name)
+    ds = device_scene(name)
+    dim, cam, cfg = small_view(s, width, anti_alias=True, seed=1)
+    frames = []
+    for chains in ("1", "2", "4"):
+        monkeypatch.setenv("RT_WF_CHAINS", chains)
+        frames.append(ds.render(dim, cam, cfg, count_work=True))
+    monkeypatch.delenv("RT_WF_CHAINS", raising=False)
+    for r in frames[1:]:
+        assert np.array_equal(r["color"], frames[0]["color"]) and np.array_equal(r["hit_id"], frames[0]["hit_id"])
+        assert np.array_equal(r["distance"], frames[0]["distance"]) and np.array_equal(r["rgb"], frames[0]["rgb"])
+        for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_aa", "shade_evals", "tri_tests", "box_tests", "stack_overflows"):
+            assert r["counters"][k] == frames[0]["counters"][k], (name, k)
+
+
 def test_queue_overflow_falls_back_to_the_persistent_kernel(render_mod, scene_cache, monkeypatch):
     s = scene_cache("glass_monkey")
     dim, cam, cfg = small_view(s, 200, anti_alias=True, seed=1)
