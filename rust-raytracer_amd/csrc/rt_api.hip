@@ -507,7 +507,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
         wa.rjobs = queue(s->wf_rjobs, n, JQ_NF); wa.sjobs = queue(s->wf_sjobs, n, JQ_NF);
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
-        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = refill_min(); wa.descend_frac = descend_frac();
+        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = std::getenv("RT_REFILL_MIN") ? refill_min() : 24u; wa.descend_frac = descend_frac();   // (measured: 24 free lanes before the walk kernel refills, 16 in the persistent kernel)
         wa.contrib = queue(s->wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
