@@ -148,7 +148,10 @@ struct TraceArgs {
 };
 
 template <uint32_t F, bool COUNT>
-__global__ void __launch_bounds__((F & RTF_LDS_BVH) ? 512 : 64)
+// At least two waves per SIMD, i.e. at most 256 registers: left alone the area-light variants take 448
+// and run one wave per SIMD, which was measured 15 % (light_room) to 40 % (monkey_1) slower; three
+// waves per SIMD spill too much and are slower again.
+__global__ void __launch_bounds__((F & RTF_LDS_BVH) ? 512 : 64) __attribute__((amdgpu_waves_per_eu(2)))
 k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
     const uint32_t queued = a.round > 0 ? min(*a.in_count, a.queue_cap) : 0u;
     if (a.round > 0 && queued == 0) return;                         // nothing was handed on: uniform exit
