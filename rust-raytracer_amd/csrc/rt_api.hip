@@ -500,7 +500,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         if ((e = s->wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if (s->ds.has_background && (e = s->wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
         if ((e = s->wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
-        if ((e = s->wf_overflow.ensure((size_t)s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;
+        if ((e = s->wf_overflow.ensure((size_t)4 * s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;   // per chain: a walk launch with up to 2048 threads per CU
         if ((e = s->wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
         HIP_TRY(hipMemsetAsync(s->wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
         s->wf_cap = (uint32_t)n;
@@ -540,7 +540,13 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
             wa.hit_count = (unsigned int*)s->wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             for (uint32_t c = 0; c < chains; ++c) {
                 hipStream_t cs = c == 0 ? stream : s->chain_stream[c - 1];
-                const uint32_t cus = std::max(1u, (uint32_t)s->num_cus / chains);
+                // CUs for the chain's walk kernel (one workgroup fills a CU's LDS).  Two chains: three
+                // quarters each - the walks of the two chains rarely coincide, and when they do the
+                // later one's surplus workgroups queue (measured 54.7 ms at one half, 53.7 ms at 3/4,
+                // 56.4 ms at all CUs); four chains: a quarter each.
+                static const long walk_cus = [] { const char* e = std::getenv("RT_WF_WALK_CUS"); return e ? std::atol(e) : 0L; }();
+                const uint32_t share = chains == 2 ? (uint32_t)s->num_cus * 3u / 4u : (uint32_t)s->num_cus / chains;
+                const uint32_t cus = std::max(1u, walk_cus > 0 && chains > 1 ? (uint32_t)std::min<long>(walk_cus, s->num_cus) : share);
                 wa.sq_count = RT_WF_Q / chains; wa.sq_base = c * wa.sq_count;
                 wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g + c;   // (a cursor per chain)
                 wa.walk_overflow = overflow0 + (size_t)c * cus * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK);   // (a walk launch has at most 2048 threads per CU)
