@@ -229,6 +229,7 @@ constexpr uint32_t V_MESH = RTF_MESH;                                         //
 constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
 constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES | RTF_TLAS;                // one-way spheres, skybox, maps, many instances (many_balls)
 constexpr uint32_t V_CSG = RTF_CSG | RTF_FACED | RTF_IMAGES;                  // composite shapes under a skybox
+constexpr uint32_t V_AREA_MESH = V_AREA | RTF_MESH;                           // square light + mesh + maps (monkey_1..3)
 int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
     auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
     if (covers(0u)) return launch_variant<0u>(count, grid, stream, ds, rp, ta);
@@ -236,6 +237,8 @@ int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t strea
     if (covers(V_MESH)) return launch_variant<V_MESH>(count, grid, stream, ds, rp, ta);
     if (covers(V_BALLS)) return launch_variant<V_BALLS>(count, grid, stream, ds, rp, ta);
     if (covers(V_AREA)) return launch_variant<V_AREA>(count, grid, stream, ds, rp, ta);
+    if (covers(V_AREA_MESH) && ds.lds_blob_bytes) return launch_variant<V_AREA_MESH | RTF_LDS_BVH>(count, grid, stream, ds, rp, ta);
+    if (covers(V_AREA_MESH)) return launch_variant<V_AREA_MESH>(count, grid, stream, ds, rp, ta);
     if (covers(V_CSG)) return launch_variant<V_CSG>(count, grid, stream, ds, rp, ta);
     return launch_variant<RTF_ALL | RTF_TLAS>(count, grid, stream, ds, rp, ta);
 }
