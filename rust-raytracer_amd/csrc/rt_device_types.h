@@ -245,5 +245,8 @@ struct DCounters {             // mirrors RtCounters' first ten fields
     // number of loop trips a wave made and the number of lanes that had work in them
     unsigned long long prof[16];
 };
+// (The queue pipeline has no trips or phases A/B: its shade kernel files its own sections under those
+// slots - PF_TRIPS/PF_TRIP_LANES trips and hits, PF_A_ITERS.. PF_CYC_T cycles per section, see k_wf_shade -
+// and its walk kernel uses the PF_T_* slots as the persistent kernel does.)
 enum { PF_TRIPS = 0, PF_TRIP_LANES, PF_A_ITERS, PF_A_LANES, PF_T_ITERS, PF_T_LANES, PF_T_REFILLS, PF_T_REFILL_LANES,
        PF_T_LEAF_ITERS, PF_T_LEAF_LANES, PF_B_ITERS, PF_B_LANES, PF_CYC_A, PF_CYC_T, PF_CYC_B, PF_CYC_FETCH };
