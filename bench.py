@@ -40,7 +40,7 @@ abi = importlib.import_module("rust-raytracer_amd._abi")
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "glass_monkey"
-TILE_ROWS = 16
+TILE_ROWS = 8     # rows per block of the multi-GPU split (measured on 1080p: 8 balances the ranks best; 4 pays too much halo)
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, FP64 vector (half the 157.3 TF FP32 vector rate)
 HBM_PEAK_GBS = 8000.0
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times every rank's share of an n-way split of one frame, one after the other on one GPU:
 the slowest share is what an n-GPU run of the frame would take, the gather aside.
-Usage: prof_split.py [scene] [width] [height] [nranks ...]"""
+Usage: prof_split.py [scene] [width] [height] [nranks ...]   (TILE_ROWS in the environment: rows per block, default 16)"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 scn = importlib.import_module("rust-raytracer_amd.scenes")
@@ -17,7 +17,7 @@ for n in splits:
     shares = []
     for r in range(n):
         c = cfg.copy()
-        c.rank, c.nranks, c.tile_rows = r, n, 16
+        c.rank, c.nranks, c.tile_rows = r, n, int(os.environ.get("TILE_ROWS", "16"))
         best = 1e9
         for _ in range(3):
             t = time.time()
