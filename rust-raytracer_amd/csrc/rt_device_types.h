@@ -123,7 +123,13 @@ struct DCsgLeaf {
     DXform x;                  // composite-root parent space ↔ leaf primitive space
     uint32_t prim, _pad;
 };
-struct DCsgRoot { uint32_t op_begin, op_count; };
+struct DCsgRoot {
+    uint32_t op_begin, op_count;
+    // box around all leaves in the composite's own space (bounded == 0: some leaf is infinite): a ray that
+    // misses it hits no leaf, so every hit list is empty and the composite has no hit either
+    uint32_t bounded, _pad;
+    double lo[3], hi[3];
+};
 
 enum DShaderKind { DS_PHONG = 0, DS_TEXTURE, DS_REFLECTION, DS_TRANSLUCENT, DS_MIX, DS_COMPOSITE, DS_CHAIN, DS_NORMAL_MAP };
 struct DShader {

@@ -639,8 +639,32 @@ private:
                 DCsgRoot root{};
                 root.op_begin = (uint32_t)fs_.csg_ops.size();
                 uint32_t lists = 0;
+                const size_t leaf0 = fs_.csg_leaves.size();
                 csg(p.ref, identity(), identity(), 0, lists);
                 root.op_count = (uint32_t)fs_.csg_ops.size() - root.op_begin;
+                {   // box around the leaves, padded like the instance boxes of the top-level tree
+                    const double inf = std::numeric_limits<double>::infinity();
+                    V3 wlo{inf, inf, inf}, whi{-inf, -inf, -inf};
+                    bool bounded = fs_.csg_leaves.size() > leaf0;
+                    for (size_t li = leaf0; li < fs_.csg_leaves.size() && bounded; ++li) {
+                        const DCsgLeaf& leaf = fs_.csg_leaves[li];
+                        V3 lo, hi;
+                        if (!prim_bounds(fs_.prims[leaf.prim], lo, hi)) { bounded = false; break; }
+                        const double* m = leaf.x.l2w.r;
+                        for (int c = 0; c < 8; ++c) {
+                            V3 q{c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z};
+                            V3 w{m[0] * q.x + m[1] * q.y + m[2] * q.z + m[3], m[4] * q.x + m[5] * q.y + m[6] * q.z + m[7], m[8] * q.x + m[9] * q.y + m[10] * q.z + m[11]};
+                            wlo = {std::min(wlo.x, w.x), std::min(wlo.y, w.y), std::min(wlo.z, w.z)};
+                            whi = {std::max(whi.x, w.x), std::max(whi.y, w.y), std::max(whi.z, w.z)};
+                        }
+                    }
+                    if (bounded) {
+                        V3 ext = whi - wlo;
+                        double pad = 1e-6 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-9 * (std::fabs(wlo.x) + std::fabs(wlo.y) + std::fabs(wlo.z) + std::fabs(whi.x) + std::fabs(whi.y) + std::fabs(whi.z)) + 1e-12;
+                        root.bounded = 1;
+                        put(root.lo, wlo - V3{pad, pad, pad}); put(root.hi, whi + V3{pad, pad, pad});
+                    }
+                }
                 o.kind = DP_CSG; o.ref = (uint32_t)fs_.csg_roots.size();
                 fs_.csg_roots.push_back(root);
                 break;

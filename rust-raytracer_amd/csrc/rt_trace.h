@@ -800,7 +800,14 @@ struct SceneHit {
 template <uint32_t F, bool COUNT>
 RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk) {
     if constexpr (F & RTF_CSG) {
-        if (p.kind == DP_CSG) return csg_closest<F, COUNT>(sc, sc.csg_roots[p.ref], lr, c, wk);
+        if (p.kind == DP_CSG) {
+            const DCsgRoot& root = sc.csg_roots[p.ref];
+            if (root.bounded) {                                       // most rays pass the composite by: no leaf to hit, no lists to merge
+                double tn;
+                if (!slab(root.lo, root.hi, lr.o, mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z), INFINITY, tn)) return false;
+            }
+            return csg_closest<F, COUNT>(sc, root, lr, c, wk);
+        }
     }
     Cand cc[2];
     // an un-wrapped mesh may prune by the best distance so far; wrapped primitives must see their true closest hit
