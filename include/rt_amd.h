@@ -92,7 +92,11 @@ enum {
                                   p[9] shininess                     phong.rs:4-9        */
     RT_SHADER_TEXTURE = 1,     /* ref = image                        shader/texture.rs   */
     RT_SHADER_REFLECTION = 2,  /* p[0..3) reflectivity               reflection.rs:4-6   */
-    RT_SHADER_TRANSLUCENT = 3, /* p[0..3) translucency, p[3] ior     translucent.rs:7-11 */
+    RT_SHADER_TRANSLUCENT = 3, /* p[0..3) translucency, p[3] ior     translucent.rs:7-11
+                                  p[4] != 0: the shader's earlier revision, still present as a
+                                  comment at translucent.rs:59 — one transmitted ray, no Fresnel
+                                  split; the revision the reference's gallery/glass_monkey.png
+                                  was rendered with                                        */
     RT_SHADER_MIX = 4,         /* children                           shader.rs:52-54     */
     RT_SHADER_COMPOSITE = 5,   /* weighted children                  shader.rs:77-79     */
     RT_SHADER_CHAIN = 6,       /* children                           shader.rs:114-116   */
@@ -267,10 +271,21 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam,
  * `d_aux` are device pointers.  With nranks > 1, d_rgb_out receives only this
  * rank's row blocks, compacted: owned block k (k = 0,1,…) starts at byte
  * k*tile_rows*W*3; its capacity must be rt_owned_rows_capacity()*W*3 bytes.
- * This is the entry point the multi-GPU driver and the benchmark use. */
+ * This is the entry point the multi-GPU driver and the benchmark use; pair it with
+ * rt_frame_status (below) before trusting the frame. */
 int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam,
                      const RtRenderConfig* cfg, uint8_t* d_rgb_out, RtAux* d_aux,
                      void* hip_stream);
+
+/* Completeness of asynchronous frames.  rt_render_device returns before its frame has run, so it
+ * cannot say whether a generation of rays outgrew the ray queues (rt_render and instrumented
+ * rt_render_device calls wait, notice, and redo the frame themselves).  This call blocks until the
+ * most recent rt_render_device call on `scene` has finished and returns RT_OK when no frame since the
+ * previous rt_frame_status call lost anything, else RT_ERR_CAPACITY with the number of lost rays /
+ * shadow tests in *dropped (may be NULL): such a frame is too dark where they are missing and must be
+ * rendered again — the library has enlarged the queues (or moved the scene to its other schedule,
+ * which cannot overflow) by then.  The reference has no counterpart: its recursion cannot lose rays. */
+int rt_frame_status(const RtScene* scene, uint64_t* dropped);
 
 /* ceil(ceil(H/tile_rows)/nranks)*tile_rows: rows of the compact per-rank buffer. */
 uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_rows);

@@ -974,6 +974,7 @@ struct ReflectionShader : Shadable {                                        // s
 struct TranslucentShader : Shadable {                                       // shader/translucent.rs
     Color translucency;
     double refractive_index;
+    bool legacy = false;                                                    // RtShader.p[4]: the earlier revision, see get_color
     std::pair<double, double> get_fresnel(const Intersect& it) const {      // :19-46
         double cosi = dot(it.ray.direction, it.surface_normal);
         double etai = 1.0, etat = refractive_index;
@@ -989,7 +990,7 @@ struct TranslucentShader : Shadable {                                       // s
         return {1.0 - reflectance, reflectance};
     }
     Color get_color(const Scene& scene, const Intersect& it) const override {   // :50-62
-        if (g_legacy_translucent) {
+        if (g_legacy_translucent || legacy) {
             // The revision that rendered gallery/glass_monkey.png: the line still present as a
             // comment at translucent.rs:59 — one transmitted ray, no Fresnel split.
             Ray t = it.ray.transmit_through(it.hit_point, it.surface_normal, refractive_index).with_path(sid * 4 + 1);
@@ -1257,7 +1258,7 @@ static std::unique_ptr<Built> build(const RtSceneDesc& d) {
             case RT_SHADER_TEXTURE: { auto p = std::make_shared<TextureShader>(); p->image = b->images[s.ref].get(); out = p; break; }
             case RT_SHADER_REFLECTION: { auto p = std::make_shared<ReflectionShader>(); p->reflectivity = {s.p[0], s.p[1], s.p[2]}; out = p; break; }
             case RT_SHADER_TRANSLUCENT: {
-                auto p = std::make_shared<TranslucentShader>(); p->translucency = {s.p[0], s.p[1], s.p[2]}; p->refractive_index = s.p[3]; out = p; break;
+                auto p = std::make_shared<TranslucentShader>(); p->translucency = {s.p[0], s.p[1], s.p[2]}; p->refractive_index = s.p[3]; p->legacy = s.p[4] != 0.0; out = p; break;
             }
             case RT_SHADER_MIX: {
                 auto p = std::make_shared<MixShader>();

@@ -72,8 +72,16 @@ struct RtScene {
     uint32_t wf_cap = 0;
     // A generation that does not fit the queues loses rays; the frame is then redone by the persistent
     // kernel (which hands rays on between rounds and cannot overflow) and the scene stays on it.
-    unsigned int* h_dropped = nullptr;     // pinned: rays dropped by the last queue-pipeline frame
-    bool last_used_queues = false, queue_overflowed = false;   // hand-over queues between rounds, split-sample accumulators
+    // The device keeps one running count of lost entries (never reset, wf_sticky); every queue-pipeline frame
+    // ends with a copy of it to pinned host memory.  `dropped_seen` is the value the host has acted on (by
+    // enlarging the queues or moving the scene to the persistent kernel), `dropped_reported` the value the
+    // caller has been told about through rt_frame_status.
+    DeviceBuf wf_sticky;
+    unsigned int* h_dropped = nullptr;
+    unsigned int dropped_seen = 0, dropped_reported = 0;
+    uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
+    bool last_used_queues = false, queue_overflowed = false;
+    hipEvent_t ev_done = nullptr;          // after the last command of the most recent frame
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
@@ -106,8 +114,9 @@ void rt_scene_destroy(RtScene* s) {
     for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
                          &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->lane_mem,
                          &s->wf_rays[0], &s->wf_rays[1], &s->wf_shadows[0], &s->wf_shadows[1], &s->wf_rjobs, &s->wf_sjobs, &s->wf_contrib,
-                         &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars}) b->release();
+                         &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars, &s->wf_sticky}) b->release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     for (auto& e : s->chain_join) if (e) (void)hipEventDestroy(e);
     if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
     for (auto& st : s->chain_stream) if (st) (void)hipStreamDestroy(st);
@@ -133,6 +142,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     RtScene* s = new (std::nothrow) RtScene();
     if (!s) return fail(RT_ERR_DEVICE, "out of host memory");
     s->device = device;
+    if (const char* e = std::getenv("RT_WF_SCALE")) { long v = std::atol(e); if (v >= 1 && v <= 32) s->wf_scale = (uint32_t)v; }   // tests: start with small queues
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
     DScene& d = s->ds;
@@ -177,7 +187,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
         s->lds_limit = lds_max > 0 ? (uint32_t)lds_max : 65536u;
         d.lds_blob = nullptr; d.lds_blob_bytes = 0;
-        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + RT_LDS_FIXED_BYTES(512u) <= s->lds_limit) {
+        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + std::max<size_t>(RT_LDS_FIXED_BYTES(512u), RT_WF_WALK_FIXED_BYTES(1024u)) <= s->lds_limit) {
             rc = upload(fs.lds_blob, s->owned, &d.lds_blob);
             if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
             d.lds_blob_bytes = (uint32_t)fs.lds_blob.size();
@@ -190,6 +200,8 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     for (auto& e : s->chain_join)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
     if (hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipEventCreate failed"); }
+    if (s->wf_sticky.ensure(16) != RT_OK || hipMemset(s->wf_sticky.p, 0, 16) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipMalloc failed"); }
     if (hipHostMalloc((void**)&s->h_dropped, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipHostMalloc failed"); }
     *s->h_dropped = 0;
     *out = s;
@@ -278,7 +290,7 @@ int wf_launch(int which, uint32_t features, bool count, uint32_t grid, hipStream
 int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {   // num_cus: the chain's share of the CUs
     const bool lds_bvh = ds.lds_blob_bytes != 0;
     const uint32_t block = lds_bvh ? 1024u : 256u, grid = lds_bvh ? num_cus : num_cus * 8u;
-    const uint32_t lds = block * RT_WF_LDS_STACK * 4u + 2048u + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
+    const uint32_t lds = RT_WF_WALK_FIXED_BYTES(block) + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
     const void* fn = lds_bvh ? (count ? (const void*)k_wf_walk<true, true> : (const void*)k_wf_walk<true, false>)
                              : (count ? (const void*)k_wf_walk<false, true> : (const void*)k_wf_walk<false, false>);
     if (lds > 48u * 1024u) {
@@ -298,11 +310,11 @@ int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScen
 }
 // u32 words of the pipeline's scalar block, per pass: queue fill [generation][rays, shadow tests], walk list fill and cursor per generation
 constexpr uint32_t WF_MAX_GEN = RT_MAX_ROUNDS + 2;
+constexpr size_t WF_CAP_MAX = (size_t)1 << 26;      // entries per queue array
 constexpr uint32_t WF_N = 0, WF_WALK_COUNT = WF_N + 2 * RT_WF_Q * (WF_MAX_GEN + 1), WF_WALK_NEXT = WF_WALK_COUNT + RT_WF_Q * (WF_MAX_GEN + 1),
                    WF_PASS_WORDS = WF_WALK_NEXT + RT_WF_Q * (WF_MAX_GEN + 1);
 constexpr uint32_t WF_HIT_COUNT = 2 * WF_PASS_WORDS;            // per pass 2 * RT_WF_Q * (WF_MAX_GEN + 1) words
-constexpr uint32_t WF_DROPPED = WF_HIT_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1);
-constexpr size_t WF_SCALAR_BYTES = (WF_DROPPED + 4) * 4;
+constexpr size_t WF_SCALAR_BYTES = (WF_HIT_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1) + 4) * 4;
 // RT_PATH=persistent forces the persistent kernel for every scene (read at every frame, so that a
 // test can render the same scene down both schedules in one process).
 bool use_wavefront(uint32_t features) {
@@ -420,7 +432,14 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     // hand-over queues between rounds, one accumulator per sample slot
     const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 22), 1u << 25);
     const size_t acc_slots = npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u);
-    const bool wavefront = use_wavefront(s->ds.features) && !s->queue_overflowed;
+    // queue pipeline: s->wf_scale entries per pixel (and queue) of this rank's share, every queue cut into RT_WF_Q sub-queues
+    uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)W * num_rows * s->wf_scale, 1u << 20), WF_CAP_MAX);
+    if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, (long)WF_CAP_MAX); }   // tests: provoke an overflow
+    wf_cap = (wf_cap / RT_WF_Q) * RT_WF_Q;
+    // The pipeline runs recursion_depth + 1 generations out of a scalar block sized for WF_MAX_GEN, and
+    // generation 0 (one ray per pixel) must fit the queues: frames beyond either run on the persistent kernel.
+    const bool wavefront = use_wavefront(s->ds.features) && !s->queue_overflowed && rc.recursion_depth + 1 <= WF_MAX_GEN &&
+                           (size_t)W * num_rows <= wf_cap;
     if (!wavefront) for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
     {
         bool fresh = s->acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
@@ -492,8 +511,6 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         return RT_OK;
     };
     // ---- the other schedule: ray queues in HBM, one generation of rays per set of launches
-    uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 16, 1u << 22), 1u << 26);
-    if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, 1L << 26); }   // tests: provoke an overflow
     WfArgs wa{};
     if (wavefront) {
         const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
@@ -514,7 +531,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wa.contrib = queue(s->wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
         wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
-        wa.dropped = (unsigned int*)s->wf_scalars.p + WF_DROPPED;
+        wa.dropped = (unsigned int*)s->wf_sticky.p;
         wa.rows = (const uint32_t*)s->rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
         { const char* dbg = std::getenv("RT_WF_DEBUG"); wa.debug = dbg ? (uint32_t)std::atoi(dbg) : 0u; }
     }
@@ -611,10 +628,35 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     }
     HIP_TRY(hipEventRecord(s->ev[3], stream));
     s->last_used_queues = wavefront;
-    if (wavefront) HIP_TRY(hipMemcpyAsync(s->h_dropped, (unsigned int*)s->wf_scalars.p + WF_DROPPED, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    if (wavefront) HIP_TRY(hipMemcpyAsync(s->h_dropped, s->wf_sticky.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(s->ev_done, stream));
     s->timed = true;
     s->acc_dirty = false;
     return RT_OK;
+}
+
+// Acts on entries the queue pipeline lost since the host last looked: the next frame gets queues twice
+// as large, or, when they cannot grow any further, the persistent kernel (which hands rays on between
+// rounds and cannot overflow).  Returns whether there were any.
+bool note_drops(RtScene* s) {
+    const unsigned int now = *s->h_dropped;
+    if (now == s->dropped_seen) return false;
+    s->dropped_seen = now;
+    if (s->wf_scale < 32 && !std::getenv("RT_WF_CAP")) s->wf_scale *= 2;
+    else s->queue_overflowed = true;
+    return true;
+}
+// One frame whose completeness is known on return: enqueues it, waits, and redoes it while the queue
+// pipeline reports lost entries (each attempt with larger queues, the last one on the persistent kernel).
+int render_complete_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cam, const RtRenderConfig& cfg, uint8_t* d_rgb,
+                          bool count, hipStream_t stream) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        int rc = enqueue_frame(s, dim, cam, cfg, d_rgb, count, stream);
+        if (rc != RT_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (!s->last_used_queues || !note_drops(s)) { s->dropped_reported = s->dropped_seen; return RT_OK; }
+    }
+    return fail(RT_ERR_CAPACITY, "rt_render: the frame keeps overflowing the ray queues");
 }
 
 void fill_counters(RtCounters& out, const DCounters& c) {
@@ -643,18 +685,11 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     bool count = d_aux && d_aux->count_work;
-    // an earlier asynchronous frame that lost rays (known once it has finished) moves the scene to the persistent kernel
-    if (s->last_used_queues && *s->h_dropped > 0) s->queue_overflowed = true;
-    rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, count, stream);
+    // an earlier asynchronous frame that lost rays (known once it has finished): larger queues from now on
+    if (s->last_used_queues) (void)note_drops(s);
+    if (count) rc = render_complete_frame(s, *dim, *cam, *cfg, d_rgb_out, true, stream);   // this variant of the call synchronises anyway
+    else rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, false, stream);
     if (rc != RT_OK) return rc;
-    if (count && s->last_used_queues) {   // this variant of the call synchronises anyway: redo a frame that lost rays at once
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (*s->h_dropped > 0) {
-            s->queue_overflowed = true;
-            rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, count, stream);
-            if (rc != RT_OK) return rc;
-        }
-    }
     if (d_aux) {
         const size_t npix = (size_t)dim->width * dim->height;
         if (d_aux->color) HIP_TRY(hipMemcpyAsync(d_aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -668,7 +703,6 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
             HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
-            if (s->last_used_queues) c.stack_overflows += *s->h_dropped;
             fill_counters(d_aux->counters, c);
         }
     }
@@ -692,6 +726,23 @@ int rt_last_timings(const RtScene* scene, double* ms_pass1, double* ms_aa, doubl
     return RT_OK;
 }
 
+int rt_frame_status(const RtScene* scene, uint64_t* dropped) {
+    if (!scene) return fail(RT_ERR_INVALID_ARG, "rt_frame_status: null scene");
+    RtScene* s = const_cast<RtScene*>(scene);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (dropped) *dropped = 0;
+    if (!s->timed) return fail(RT_ERR_INVALID_ARG, "rt_frame_status: no frame rendered yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_done));
+    if (s->last_used_queues) (void)note_drops(s);
+    const unsigned int lost = s->dropped_seen - s->dropped_reported;
+    s->dropped_reported = s->dropped_seen;
+    if (dropped) *dropped = lost;
+    if (lost) return fail(RT_ERR_CAPACITY, "a ray generation outgrew the queues: the frame lacks " + std::to_string(lost) +
+                                           " rays / shadow tests; render it again (the queues have been enlarged)");
+    return RT_OK;
+}
+
 int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg,
               uint8_t* rgb_out, RtAux* aux) {
     int rc = check_args(scene, dim, cam, cfg);
@@ -708,15 +759,9 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
         if (e != RT_OK) return e;
         HIP_TRY(hipMemsetAsync(s->rgb_full.p, 0, rgb_bytes, nullptr));
         bool count = aux && aux->count_work;
-        rc = enqueue_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
+        if (s->last_used_queues) (void)note_drops(s);
+        rc = render_complete_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
         if (rc != RT_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
-        if (s->last_used_queues && *s->h_dropped > 0) {   // a generation outgrew the queues: redo the frame with the persistent kernel
-            s->queue_overflowed = true;
-            HIP_TRY(hipMemsetAsync(s->rgb_full.p, 0, rgb_bytes, nullptr));
-            rc = enqueue_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
-            if (rc != RT_OK) return rc;
-        }
         HIP_TRY(hipMemcpy(rgb_out, s->rgb_full.p, rgb_bytes, hipMemcpyDeviceToHost));
         if (aux) {
             if (aux->color) HIP_TRY(hipMemcpy(aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -728,7 +773,6 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
-            if (s->last_used_queues) c.stack_overflows += *s->h_dropped;
             fill_counters(aux->counters, c);
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
@@ -765,7 +809,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
                 }
                 std::fprintf(stderr, "\n");
             }
-            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_cap / RT_WF_Q), ws[WF_DROPPED]);
+            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_cap / RT_WF_Q), *s->h_dropped);
         }
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];

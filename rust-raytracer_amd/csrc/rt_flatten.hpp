@@ -148,7 +148,10 @@ struct FlatScene {
 struct BuildTri { V3 lo, hi, c; uint32_t face; };
 struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
-inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes, int node_idx, uint32_t first, uint32_t count, int depth) {
+// `max_depth`: the walk that will use the tree keeps one stack entry per level, so a tree may not grow
+// deeper than that stack; a subtree that reaches the limit becomes a leaf if its count still fits the
+// 3-bit leaf count of a child reference, else the scene is refused.
+inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes, int node_idx, uint32_t first, uint32_t count, int depth, int max_depth) {
     const double inf = std::numeric_limits<double>::infinity();
     V3 lo{inf, inf, inf}, hi{-inf, -inf, -inf}, clo = lo, chi = hi;
     for (uint32_t i = first; i < first + count; ++i) {
@@ -160,7 +163,8 @@ inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes
     }
     nodes[node_idx].lo = lo; nodes[node_idx].hi = hi;
     const uint32_t LEAF = 2;
-    if (count <= LEAF || depth >= RT_BVH_STACK - 2) { nodes[node_idx].first = first; nodes[node_idx].count = count; return; }
+    if (count > LEAF && depth >= max_depth && count > 7u) throw Unsupported("bounding hierarchy deeper than the device walk stack");
+    if (count <= LEAF || depth >= max_depth) { nodes[node_idx].first = first; nodes[node_idx].count = count; return; }
     auto area = [](V3 a, V3 b) { V3 d = b - a; return 2.0 * (d.x * d.y + d.y * d.z + d.z * d.x); };
     const int BINS = 16;
     double best_cost = inf; int best_axis = -1, best_bin = -1;
@@ -212,8 +216,8 @@ inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes
     int l = (int)nodes.size(); nodes.emplace_back();
     int r = (int)nodes.size(); nodes.emplace_back();
     nodes[node_idx].left = l; nodes[node_idx].right = r;
-    build_bvh(tris, nodes, l, first, mid - first, depth + 1);
-    build_bvh(tris, nodes, r, mid, first + count - mid, depth + 1);
+    build_bvh(tris, nodes, l, first, mid - first, depth + 1, max_depth);
+    build_bvh(tris, nodes, r, mid, first + count - mid, depth + 1, max_depth);
 }
 
 inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& m) {
@@ -232,7 +236,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     }
     std::vector<BuildNode> bn(1);
     bn.reserve(2 * m.num_faces + 2);
-    build_bvh(bt, bn, 0, 0, m.num_faces, 0);
+    build_bvh(bt, bn, 0, 0, m.num_faces, 0, RT_BVH_STACK - 2);
     // pad boxes so that slab-test rounding can never cull a triangle lying on a box face
     V3 ext = bn[0].hi - bn[0].lo;
     double pad = 1e-9 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-300;
@@ -504,7 +508,7 @@ private:
         if (bt.size() < RT_TLAS_MIN_INSTANCES) { fs_.tlas_unbounded.clear(); return; }
         std::vector<BuildNode> bn(1);
         bn.reserve(2 * bt.size() + 2);
-        build_bvh(bt, bn, 0, 0, (uint32_t)bt.size(), 0);
+        build_bvh(bt, bn, 0, 0, (uint32_t)bt.size(), 0, RT_TLAS_STACK - 2);
         for (const BuildTri& b : bt) fs_.tlas_index.push_back(b.face);
         std::vector<int> interior_index(bn.size(), -1);
         std::vector<int> order;

@@ -424,6 +424,13 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 break;
             }
             case DS_TRANSLUCENT: {                                                            // shader/translucent.rs:50-62
+                if (sh.p[4] != 0.0) {
+                    // the shader's earlier revision (kept as a comment at translucent.rs:59): the colour of the
+                    // transmitted ray alone, unscaled, its contribution scaled by `translucency`
+                    if (sink.room()) sink.ray(hit.p, transmit_dir(ray_dir, n, sh.p[3]), win, cin * ld3(sh.p), cur * 4 + 1);
+                    value = mk3(0.0, 0.0, 0.0);
+                    break;
+                }
                 double kt, kr;
                 fresnel(ray_dir, n, sh.p[3], kt, kr);
                 if (kt > 0.0 && sink.room()) sink.ray(hit.p, transmit_dir(ray_dir, n, sh.p[3]), win * kt, cin * kt, cur * 4 + 1);

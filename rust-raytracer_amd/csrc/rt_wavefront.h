@@ -23,6 +23,7 @@
 #include "rt_kernels.h"
 
 #define RT_WF_LDS_STACK 12     // BVH walk stack entries per thread kept in LDS by k_wf_walk
+#define RT_WF_WALK_FIXED_BYTES(threads) ((threads) * RT_WF_LDS_STACK * 4u + 2048u)   // k_wf_walk's LDS apart from the BVH blob: walk stacks, list starts
 // Every queue is cut into RT_WF_Q sub-queues with a fill counter each.  Appending costs one
 // atomic per wave on the counter; on a single counter those serialise (~12 ns each, 4-6 million
 // per generation), spread over 256 counters they do not.  Workgroup b reads and appends to
@@ -163,7 +164,13 @@ RT_DEV void wf_flush(DCounters* g, const Work<COUNT>& wk, unsigned long long cam
 __global__ void __launch_bounds__(256)
 k_wf_generate(DRenderParams rp, WfArgs a) {
     const uint32_t W = rp.cam.width;
-    const uint32_t total = a.mode == 0 ? W * a.num_rows : min(*a.aa_count * rp.aa_rays, a.cap / 2);
+    // (pass 1: the host has checked that the frame's pixels fit the queues.  AA resolve: the number of
+    // flagged pixels is only known on the device; samples that do not fit are counted as lost, which
+    // makes the host redo the frame with larger queues)
+    const unsigned long long aa_want = a.mode == 0 ? 0ull : (unsigned long long)*a.aa_count * rp.aa_rays;
+    const uint32_t total = a.mode == 0 ? W * a.num_rows : (uint32_t)min(aa_want, (unsigned long long)a.cap);
+    if (a.mode != 0 && aa_want > a.cap && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(a.dropped, (unsigned int)min(aa_want - a.cap, 0x7FFFFFFFull));
     // item i goes to sub-queue i % RT_WF_Q
     if (blockIdx.x == 0) {
         for (uint32_t sq = threadIdx.x; sq < RT_WF_Q; sq += blockDim.x) {

@@ -54,11 +54,20 @@ def render_frame(render_local, width, height, tile_rows, device, group=None):
     return None
 
 
-def hip_render_local(device_scene, dim, cam, cfg):
-    """render_local callback backed by rt_render_device on torch's current stream."""
+def hip_render_local(device_scene, dim, cam, cfg, check=True):
+    """render_local callback backed by rt_render_device on torch's current stream.
+
+    With `check` the callback waits for the frame and renders it again if rt_frame_status reports lost
+    rays; a caller that pipelines frames passes check=False and calls `device_scene.frame_dropped()`
+    itself before it uses them."""
     def fn(local, rank, world, tile_rows):
         c = cfg.copy()
         c.rank, c.nranks, c.tile_rows = rank, world, tile_rows
         stream = torch.cuda.current_stream(local.device).cuda_stream
-        device_scene.render_device(dim, cam, c, local.data_ptr(), stream)
+        for _ in range(8):
+            device_scene.render_device(dim, cam, c, local.data_ptr(), stream)
+            if check and device_scene.frame_dropped():
+                continue          # a ray generation outgrew the queues: the library has enlarged them, render again
+            return
+        raise RuntimeError("the frame keeps overflowing the ray queues")
     return fn

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")   # RT_AMD_LIB: another build of the same library (kernel tuning experiments)
 
 EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
-           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings"]
+           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status"]
 
 _lib = None
 
@@ -46,6 +46,8 @@ def hip_lib():
         lib.rt_owned_rows_capacity.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.rt_last_timings.restype = C.c_int
         lib.rt_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.rt_frame_status.restype = C.c_int
+        lib.rt_frame_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -104,6 +106,14 @@ class DeviceScene:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         _check(hip_lib().rt_last_timings(self._handle, C.byref(a), C.byref(b), C.byref(c)))
         return {"pass1": a.value, "aa": b.value, "encode": c.value}
+
+    def frame_dropped(self):
+        """rt_frame_status: waits for the last rt_render_device frame; rays it (or frames since the last call) lost."""
+        n = C.c_uint64()
+        rc = hip_lib().rt_frame_status(self._handle, C.byref(n))
+        if rc not in (RT_OK, 5):
+            _check(rc)
+        return int(n.value)
 
     def close(self):
         if self._handle:

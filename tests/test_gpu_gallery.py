@@ -1,0 +1,89 @@
+"""The HIP render path against the reference's own output images (gallery/*.png of the reference,
+committed as fixtures under tests/golden/), at their full 1000x1000 size, through the C ABI.
+
+glass_monkey.png was rendered by an earlier revision of tests/mesh_test.rs / src/shader/translucent.rs:
+glass() weighted (0.5, 0.5) and TranslucentShader cast only the transmitted ray (the line that survives
+as a comment at translucent.rs:59).  The scene description carries that revision as RtShader.p[4] = 1.
+Every pixel the AA pass did not re-sample is deterministic and must be identical to the byte; the
+others carry the reference's unseedable thread_rng jitter and are compared as block means."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gallery(name):
+    return np.asarray(Image.open(os.path.join(GOLDEN, f"gallery_{name}.png")).convert("RGB"))
+
+
+def blocks(img, b=16):
+    h, w, _ = img.shape
+    return img[:h // b * b, :w // b * b].astype(float).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+def legacy_glass_monkey(scenes_mod, abi_mod):
+    s = scenes_mod.Scene("glass_monkey")
+    d = C.cast(s.desc, C.POINTER(abi_mod.RtSceneDesc)).contents
+    glass = d.shaders[d.nodes[8].shader]
+    assert glass.kind == 5 and glass.num_children == 2          # Composite[(0.1, Reflection), (0.9, Translucent)]
+    d.shader_child_weight[glass.first_child] = 0.5
+    d.shader_child_weight[glass.first_child + 1] = 0.5
+    translucent = d.shaders[d.shader_child_idx[glass.first_child + 1]]
+    assert translucent.kind == 3
+    translucent.p[4] = 1.0
+    return s
+
+
+def test_glass_monkey_equals_the_reference_image_on_every_deterministic_pixel(scenes_mod, abi_mod, render_mod):
+    gold = gallery("glass_monkey")
+    assert gold.shape == (1000, 1000, 3)
+    s = legacy_glass_monkey(scenes_mod, abi_mod)
+    dim, cam, cfg = s.view()
+    assert (dim.width, dim.height, cfg.anti_alias, cfg.aa_rays, cfg.recursion_depth) == (1000, 1000, 1, 5, 20)
+    ds = render_mod.DeviceScene(s, device=0)
+    r = ds.render(dim, cam, cfg, count_work=True)
+    ds.close()
+    assert r["counters"]["stack_overflows"] == 0
+    det = r["aa_mask"] == 0
+    diff = np.abs(r["rgb"].astype(int) - gold.astype(int)).max(axis=2)
+    assert det.sum() > 800000
+    assert ((r["hit_id"] == 8) & det).sum() > 20000, "deterministic glass pixels must be part of the comparison"
+    assert diff[det].max() == 0, f"{(diff[det] > 0).sum()} deterministic pixels differ from the reference image"
+    # AA pixels: other jitter, same distribution
+    aa = ~det
+    assert aa.sum() > 50000
+    assert abs(r["rgb"][aa].astype(float).mean() - gold[aa].astype(float).mean()) < 1.0
+    d = np.abs(blocks(r["rgb"]) - blocks(gold))
+    assert d.max() < 12.0 and d.mean() < 0.25, (d.max(), d.mean())
+
+
+# light_room.png and monkey_1.png are stochastic (square area light, thread_rng) and were rendered by a
+# revision of src/light.rs whose penumbrae differ visibly from what the present subdivide_illumination
+# (light.rs:248-298) produces: smooth where today's 4-probe shortcut leaves dark cores and bright rims
+# (SquareLight still carries that older sampling as dead code: SAMPLE_RATE = 400, get_sample :355-363).
+# Outside the penumbrae the images agree to the noise of the estimator, which is what pins the light's
+# intensity law, Phong under an area light, the mirror wall, the cube's texture atlas, the mesh under
+# the same light and the tiled / bump-mapped floor.  Measured on this build (16x16 block means, 3844
+# blocks): two seeds of the device render differ by <= 1 LSB in 99.6 % / 96.5 % of the blocks
+# (light_room / monkey_1); device vs gallery: 86.5 % / 76.1 % within 1 LSB, 94.8 % / 94.9 % within 3,
+# 99.0 % / 97.7 % within 8, whole-image channel means within 0.1 / 0.35 LSB, correlation 0.9996.
+@pytest.mark.parametrize("name,within1,within3,within8", [("light_room", 0.84, 0.93, 0.98), ("monkey_1", 0.73, 0.93, 0.965)])
+def test_area_light_scenes_agree_with_the_reference_images_in_block_means(name, within1, within3, within8, scenes_mod, render_mod):
+    gold = gallery(name)
+    assert gold.shape == (1000, 1000, 3)
+    s = scenes_mod.Scene(name)
+    dim, cam, cfg = s.view(width=1000, height=1000, anti_alias=True, seed=1)
+    ds = render_mod.DeviceScene(s, device=0)
+    r = ds.render(dim, cam, cfg, count_work=True)
+    ds.close()
+    assert r["counters"]["stack_overflows"] == 0
+    d = np.abs(blocks(r["rgb"]) - blocks(gold)).max(axis=2)
+    assert (d <= 1.0).mean() >= within1 and (d <= 3.0).mean() >= within3 and (d <= 8.0).mean() >= within8, \
+        ((d <= 1.0).mean(), (d <= 3.0).mean(), (d <= 8.0).mean())
+    assert np.abs(r["rgb"].reshape(-1, 3).mean(axis=0) - gold.reshape(-1, 3).astype(float).mean(axis=0)).max() < 0.6
+    assert np.corrcoef(blocks(r["rgb"]).ravel(), blocks(gold).ravel())[0, 1] > 0.999

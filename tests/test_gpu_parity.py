@@ -262,3 +262,60 @@ def test_queue_overflow_falls_back_to_the_persistent_kernel(render_mod, scene_ca
         assert np.array_equal(r["color"], want["color"]) and np.array_equal(r["hit_id"], want["hit_id"])
     assert got["counters"]["stack_overflows"] == 0
     assert got["counters"]["rays_total"] == want["counters"]["rays_total"]
+
+
+def test_aa_generation_overflow_redoes_the_frame(render_mod, scene_cache, monkeypatch):
+    """Queues that hold pass 1 but not the AA resolve's generation 0 (every interior hit pixel flagged,
+    aa_rays samples each): the lost samples must be noticed and the frame redone, not averaged in as black."""
+    s = scene_cache("basic_setup_scene")
+    dim, cam, cfg = s.view(width=256, height=256, anti_alias=True, seed=1, aa_threshold=0.0, aa_rays=16)
+    ref = render_mod.DeviceScene(s, device=0)
+    want = ref.render(dim, cam, cfg, count_work=True)
+    ref.close()
+    assert want["counters"]["rays_aa"] > 65536          # the AA generation alone exceeds the queues below
+    monkeypatch.setenv("RT_WF_CAP", "65536")
+    ds = render_mod.DeviceScene(s, device=0)
+    got = ds.render(dim, cam, cfg, count_work=True)
+    ds.close()
+    monkeypatch.delenv("RT_WF_CAP", raising=False)
+    assert np.array_equal(got["color"], want["color"]) and np.array_equal(got["rgb"], want["rgb"])
+    assert got["counters"]["rays_total"] == want["counters"]["rays_total"]
+
+
+def test_queues_grow_after_an_overflow_and_the_async_path_reports_it(render_mod, scene_cache, monkeypatch):
+    import torch
+    s = scene_cache("glass_monkey")
+    dim, cam, cfg = small_view(s, 1200, anti_alias=True, seed=1)      # (queues never shrink below 2^20 entries: a frame larger than that)
+    ref = render_mod.DeviceScene(s, device=0)
+    want = ref.render(dim, cam, cfg, want_aux=False)["rgb"]
+    ref.close()
+    monkeypatch.setenv("RT_WF_SCALE", "1")               # one queue entry per pixel: glass needs several
+    ds = render_mod.DeviceScene(s, device=0)
+    monkeypatch.delenv("RT_WF_SCALE", raising=False)
+    buf = torch.zeros((dim.height, dim.width, 3), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    lost = []
+    for _ in range(8):                                    # what a caller of the asynchronous entry point does
+        ds.render_device(dim, cam, cfg, buf.data_ptr(), stream)
+        lost.append(ds.frame_dropped())
+        if lost[-1] == 0:
+            break
+    assert lost[0] > 0 and lost[-1] == 0, lost
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), want)
+    # the synchronous entry point redoes such a frame by itself
+    monkeypatch.setenv("RT_WF_SCALE", "1")
+    ds2 = render_mod.DeviceScene(s, device=0)
+    monkeypatch.delenv("RT_WF_SCALE", raising=False)
+    assert np.array_equal(ds2.render(dim, cam, cfg, want_aux=False)["rgb"], want)
+    ds.close(); ds2.close()
+
+
+def test_recursion_deeper_than_the_queue_pipeline_runs_on_the_other_schedule(device_scene, scene_cache, oracle):
+    """recursion_depth + 1 generations beyond what the pipeline's scalar block holds: such frames take the persistent kernel."""
+    s = scene_cache("scene_test_2")
+    dim, cam, cfg = small_view(s, 96, anti_alias=False, seed=1, recursion_depth=60)
+    got = device_scene("scene_test_2").render(dim, cam, cfg, count_work=True)
+    want = oracle.render(s, dim, cam, cfg)
+    check(got, want, "scene_test_2 depth 60")
+    assert got["counters"]["rays_total"] == want["counters"]["rays_total"]

@@ -66,3 +66,24 @@ def test_hand_checked_wall_pixels(legacy_scene, oracle):
     r = oracle.render(legacy_scene, dim, cam, cfg)
     assert tuple(r["rgb"][20, 500]) == (130, 0, 0)
     assert tuple(r["rgb"][950, 30]) == (109, 109, 0)
+
+
+# ---- the area-light images of the reference's gallery (statistical: thread_rng, and a light-sampling
+# revision whose penumbrae differ from today's subdivide_illumination; see tests/test_gpu_gallery.py) ----
+def _blocks(img, b=16):
+    h, w, _ = img.shape
+    return img[:h // b * b, :w // b * b].astype(float).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+@pytest.mark.parametrize("name,within1,within3", [("light_room", 0.80, 0.91), ("monkey_1", 0.68, 0.90)])
+def test_oracle_agrees_with_the_area_light_gallery_images_in_block_means(name, within1, within3, scenes_mod, oracle):
+    gold = np.asarray(Image.open(os.path.join(os.path.dirname(GOLD), f"gallery_{name}.png")).convert("RGB"))
+    s = scenes_mod.Scene(name)
+    # every 5th block of 16 rows: 200 of the 1000 rows
+    dim, cam, cfg = s.view(width=1000, height=1000, anti_alias=True, seed=1, rank=2, nranks=5, tile_rows=16)
+    r = oracle.render(s, dim, cam, cfg)
+    assert r["assert_failures"] == 0
+    rows = np.array([y for y in range(1000) if (y // 16) % 5 == 2 and y // 16 < 62])
+    d = np.abs(_blocks(r["rgb"][rows]) - _blocks(gold[rows])).max(axis=2)
+    assert (d <= 1.0).mean() >= within1 and (d <= 3.0).mean() >= within3, ((d <= 1.0).mean(), (d <= 3.0).mean())
+    assert np.abs(r["rgb"][rows].reshape(-1, 3).mean(axis=0) - gold[rows].reshape(-1, 3).astype(float).mean(axis=0)).max() < 1.0
