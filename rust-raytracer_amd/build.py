@@ -1,6 +1,7 @@
 """Builds the native pieces in-tree (the .so files travel to the GPU box with the tree).
 
-  csrc/librt_amd.so            HIP render path for gfx950 (hipcc cross-compiles without a GPU)
+  csrc/librt_amd.so            HIP render path for gfx950 (hipcc cross-compiles without a GPU); the kernel
+                               variants under csrc/variants/ are separate translation units built in parallel
   host/libraytracer_host.so    C++ mirror of the reference API + the transcribed test scenes
 """
 import os
@@ -32,12 +33,29 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_hip(force=False):
+def build_hip(force=False, jobs=None):
+    """csrc/rt_api.hip and every csrc/variants/*.hip compile to objects side by side (csrc/obj/), then link."""
+    from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(HERE, "csrc")
-    sources = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".hpp"))]
-    sources.append(os.path.join(INCLUDE, "rt_amd.h"))
-    if force or _newer(HIP_LIB, sources):
-        _run(["hipcc", *HIP_FLAGS, "-I" + INCLUDE, "-o", HIP_LIB, os.path.join(src_dir, "rt_api.hip")])
+    obj_dir = os.path.join(src_dir, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".h", ".hpp"))]
+    headers.append(os.path.join(INCLUDE, "rt_amd.h"))
+    var_dir = os.path.join(src_dir, "variants")
+    sources = [os.path.join(src_dir, "rt_api.hip")] + sorted(os.path.join(var_dir, f) for f in os.listdir(var_dir) if f.endswith(".hip"))
+    flags = [f for f in HIP_FLAGS if f != "-shared"]
+    todo, objects = [], []
+    for src in sources:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objects.append(obj)
+        if force or _newer(obj, headers + [src]):
+            todo.append(["hipcc", *flags, "-c", "-I" + INCLUDE, "-o", obj, src])
+    if todo:
+        jobs = jobs or min(len(todo), max(1, min(16, os.cpu_count() or 1)))
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            list(pool.map(_run, todo))
+    if todo or _newer(HIP_LIB, objects):
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objects])
     return HIP_LIB
 
 

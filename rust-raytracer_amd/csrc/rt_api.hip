@@ -15,8 +15,8 @@
 
 #include "rt_amd.h"
 #include "rt_flatten.hpp"
-#include "rt_kernels.h"
-#include "rt_wavefront.h"
+#define RT_FRAME_KERNELS   // this file holds the small per-frame kernels (generation 0, resolve, AA, encode)
+#include "rt_variants.h"
 
 namespace {
 
@@ -30,17 +30,31 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
         if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Caller-provided device memory that buffers are carved from instead of hipMalloc (the entry point that
+// allocates nothing): a bump pointer, reset for every frame.
+struct Arena {
+    uint8_t* base = nullptr;
+    size_t capacity = 0, used = 0;
+};
+
 struct DeviceBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    Arena* arena = nullptr;            // set: memory comes out of the arena and is never freed here
     int ensure(size_t n) {
         if (n <= bytes) return RT_OK;
+        if (arena) {
+            const size_t at = (arena->used + 255u) & ~(size_t)255u;
+            if (at + n > arena->capacity) return fail(RT_ERR_CAPACITY, "frame workspace exceeds the static scratch array");
+            p = arena->base + at; bytes = n; arena->used = at + n;
+            return RT_OK;
+        }
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         HIP_TRY(hipMalloc(&p, n));
         bytes = n;
         return RT_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (p && !arena) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
 template <class T>
@@ -57,6 +71,25 @@ int upload(const std::vector<T>& v, std::vector<void*>& owned, const T** out) {
 
 }  // namespace
 
+// Device memory one frame works in.  A scene owns one (grown on demand with hipMalloc, reused from
+// frame to frame); the entry point that allocates nothing builds a temporary one over the static scratch array.
+struct Workspace {
+    DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
+    DeviceBuf queue[2], acc, acc_flags, lane_mem;
+    // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;
+    uint32_t wf_cap = 0;
+    bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
+    std::vector<uint32_t> rows_host;
+    uint32_t rows_key[5] = {0, 0, 0, 0, 0};
+    std::vector<DeviceBuf*> all() {
+        return {&color, &distance, &hit_id, &mask, &list, &samples, &rows, &scalars, &rgb_full, &queue[0], &queue[1], &acc, &acc_flags, &lane_mem,
+                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_contrib, &wf_walk_list, &wf_overflow, &wf_scalars};
+    }
+    void use(Arena* a) { for (DeviceBuf* b : all()) b->arena = a; }
+    void release() { for (DeviceBuf* b : all()) b->release(); }
+};
+
 struct RtScene {
     int device = 0;
     int num_cus = 256;
@@ -65,13 +98,7 @@ struct RtScene {
     uint32_t lds_limit = 65536;
     // per-frame workspace, grown on demand and reused across frames
     std::mutex mu;
-    DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
-    DeviceBuf queue[2], acc, acc_flags, lane_mem;
-    // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
-    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;
-    uint32_t wf_cap = 0;
-    // A generation that does not fit the queues loses rays; the frame is then redone by the persistent
-    // kernel (which hands rays on between rounds and cannot overflow) and the scene stays on it.
+    Workspace ws;
     // The device keeps one running count of lost entries (never reset, wf_sticky); every queue-pipeline frame
     // ends with a copy of it to pinned host memory.  `dropped_seen` is the value the host has acted on (by
     // enlarging the queues or moving the scene to the persistent kernel), `dropped_reported` the value the
@@ -81,10 +108,8 @@ struct RtScene {
     unsigned int dropped_seen = 0, dropped_reported = 0;
     uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
     bool last_used_queues = false, queue_overflowed = false;
+    bool last_noalloc = false;             // the most recent frame ran in the static scratch array: its queues cannot grow
     hipEvent_t ev_done = nullptr;          // after the last command of the most recent frame
-    bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
-    std::vector<uint32_t> rows_host;
-    uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     // queue pipeline as several chains side by side: chain 0 runs on the caller's stream, the others on these
@@ -111,10 +136,8 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
-    for (DeviceBuf* b : {&s->color, &s->distance, &s->hit_id, &s->mask, &s->list, &s->samples, &s->rows, &s->scalars, &s->rgb_full,
-                         &s->queue[0], &s->queue[1], &s->acc, &s->acc_flags, &s->lane_mem,
-                         &s->wf_rays[0], &s->wf_rays[1], &s->wf_shadows[0], &s->wf_shadows[1], &s->wf_rjobs, &s->wf_sjobs, &s->wf_contrib,
-                         &s->wf_walk_list, &s->wf_overflow, &s->wf_scalars, &s->wf_sticky}) b->release();
+    s->ws.release();
+    s->wf_sticky.release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     for (auto& e : s->chain_join) if (e) (void)hipEventDestroy(e);
@@ -219,94 +242,36 @@ uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_
 
 namespace {
 
-// The trace kernel is compiled for a few feature sets; a scene runs on the smallest one that
-// covers what it contains (fewer registers and less scratch than the all-features build).
-template <uint32_t F>
-int launch_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
-    uint32_t block = 64, lds = 0;
-    if (F & RTF_LDS_BVH) { block = 512; grid = std::max(1u, grid / 8); }   // one 512-thread workgroup per CU, the BVH blob in its LDS
-    if (F & RTF_MESH) lds = RT_LDS_FIXED_BYTES(block) + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // walk stacks, job lists (+ blob)
-    if (lds > 48u * 1024u) {
-        auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea));
-    }
-    if (count) hipLaunchKernelGGL((k_trace<F, true>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
-    else hipLaunchKernelGGL((k_trace<F, false>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("k_trace launch: ") + hipGetErrorString(e));
+// Which variant (rt_variants.h) runs a scene: the smallest feature set that covers what it contains.
+int launched(const LaunchStatus& st) {
+    if (st.code != hipSuccess) return fail(RT_ERR_DEVICE, std::string(st.what) + ": " + hipGetErrorString(st.code));
     return RT_OK;
 }
-constexpr uint32_t V_MESH = RTF_MESH;                                         // rooms + meshes, point lights (glass_monkey)
-constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
-constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES | RTF_TLAS;                // one-way spheres, skybox, maps, many instances (many_balls)
-constexpr uint32_t V_CSG = RTF_CSG | RTF_FACED | RTF_IMAGES;                  // composite shapes under a skybox
-constexpr uint32_t V_AREA_MESH = V_AREA | RTF_MESH;                           // square light + mesh + maps (monkey_1..3)
 int launch_trace(uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
     auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
-    if (covers(0u)) return launch_variant<0u>(count, grid, stream, ds, rp, ta);
-    if (covers(V_MESH) && ds.lds_blob_bytes) return launch_variant<V_MESH | RTF_LDS_BVH>(count, grid, stream, ds, rp, ta);
-    if (covers(V_MESH)) return launch_variant<V_MESH>(count, grid, stream, ds, rp, ta);
-    if (covers(V_BALLS)) return launch_variant<V_BALLS>(count, grid, stream, ds, rp, ta);
-    if (covers(V_AREA)) return launch_variant<V_AREA>(count, grid, stream, ds, rp, ta);
-    if (covers(V_AREA_MESH) && ds.lds_blob_bytes) return launch_variant<V_AREA_MESH | RTF_LDS_BVH>(count, grid, stream, ds, rp, ta);
-    if (covers(V_AREA_MESH)) return launch_variant<V_AREA_MESH>(count, grid, stream, ds, rp, ta);
-    if (covers(V_CSG)) return launch_variant<V_CSG>(count, grid, stream, ds, rp, ta);
-    return launch_variant<RTF_ALL | RTF_TLAS>(count, grid, stream, ds, rp, ta);
+    if (covers(0u)) return launched(rt_launch_trace_plain(count, grid, stream, ds, rp, ta));
+    if (covers(V_MESH) && ds.lds_blob_bytes) return launched(rt_launch_trace_mesh_lds(count, grid, stream, ds, rp, ta));
+    if (covers(V_MESH)) return launched(rt_launch_trace_mesh(count, grid, stream, ds, rp, ta));
+    if (covers(V_BALLS)) return launched(rt_launch_trace_balls(count, grid, stream, ds, rp, ta));
+    if (covers(V_AREA)) return launched(rt_launch_trace_area(count, grid, stream, ds, rp, ta));
+    if (covers(V_AREA_MESH) && ds.lds_blob_bytes) return launched(rt_launch_trace_area_mesh_lds(count, grid, stream, ds, rp, ta));
+    if (covers(V_AREA_MESH)) return launched(rt_launch_trace_area_mesh(count, grid, stream, ds, rp, ta));
+    if (covers(V_CSG)) return launched(rt_launch_trace_csg(count, grid, stream, ds, rp, ta));
+    return launched(rt_launch_trace_everything(count, grid, stream, ds, rp, ta));
 }
 
 constexpr uint32_t RT_MAX_ROUNDS = 40;
 // ---- queue-pipeline path (rt_wavefront.h): per-generation launches of the feature variant that covers the scene
-template <uint32_t F>
-int wf_launch_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
-    // which: 0 analytic, 1 shade, 2 settle
-    const bool hot = ds.hot_bytes > 0;                                 // the scene's small tables fit into LDS
-    const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
-    uint32_t lds = tables;
-    if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
-    if (which == 2) lds = 4u * 640u * 8u;
-    const void* fn;
-    if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true> : (const void*)k_wf_analytic<F, false, true>)
-                             : (count ? (const void*)k_wf_analytic<F, true, false> : (const void*)k_wf_analytic<F, false, false>);
-    else if (which == 1) fn = hot ? (count ? (const void*)k_wf_shade<F, true, true> : (const void*)k_wf_shade<F, false, true>)
-                                  : (count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>);
-    else fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
-    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    void* params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
-    (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("wavefront kernel launch: ") + hipGetErrorString(e));
-    return RT_OK;
-}
-constexpr uint32_t V_NO_INLINE = (RTF_ALL | RTF_TLAS) & ~RTF_INLINE_LIGHTS;
 int wf_launch(int which, uint32_t features, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
     auto covers = [&](uint32_t v) { return (features & ~v) == 0; };
-    if (covers(0u)) return wf_launch_variant<0u>(which, count, grid, stream, ds, rp, wa);
-    if (covers(V_MESH)) return wf_launch_variant<V_MESH>(which, count, grid, stream, ds, rp, wa);
-    if (covers(V_BALLS)) return wf_launch_variant<V_BALLS>(which, count, grid, stream, ds, rp, wa);
-    if (covers(V_CSG)) return wf_launch_variant<V_CSG>(which, count, grid, stream, ds, rp, wa);
-    return wf_launch_variant<V_NO_INLINE>(which, count, grid, stream, ds, rp, wa);
+    if (covers(0u)) return launched(rt_launch_wf_plain(which, count, grid, stream, ds, rp, wa));
+    if (covers(V_MESH)) return launched(rt_launch_wf_mesh(which, count, grid, stream, ds, rp, wa));
+    if (covers(V_BALLS)) return launched(rt_launch_wf_balls(which, count, grid, stream, ds, rp, wa));
+    if (covers(V_CSG)) return launched(rt_launch_wf_csg(which, count, grid, stream, ds, rp, wa));
+    return launched(rt_launch_wf_everything(which, count, grid, stream, ds, rp, wa));
 }
-int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {   // num_cus: the chain's share of the CUs
-    const bool lds_bvh = ds.lds_blob_bytes != 0;
-    const uint32_t block = lds_bvh ? 1024u : 256u, grid = lds_bvh ? num_cus : num_cus * 8u;
-    const uint32_t lds = RT_WF_WALK_FIXED_BYTES(block) + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
-    const void* fn = lds_bvh ? (count ? (const void*)k_wf_walk<true, true> : (const void*)k_wf_walk<true, false>)
-                             : (count ? (const void*)k_wf_walk<false, true> : (const void*)k_wf_walk<false, false>);
-    if (lds > 48u * 1024u) {
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea));
-    }
-    if (lds_bvh) {
-        if (count) hipLaunchKernelGGL((k_wf_walk<true, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
-        else hipLaunchKernelGGL((k_wf_walk<true, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
-    } else {
-        if (count) hipLaunchKernelGGL((k_wf_walk<false, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
-        else hipLaunchKernelGGL((k_wf_walk<false, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("k_wf_walk launch: ") + hipGetErrorString(e));
-    return RT_OK;
+int wf_launch_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {
+    return launched(rt_launch_wf_walk(count, num_cus, stream, ds, wa));
 }
 // u32 words of the pipeline's scalar block, per pass: queue fill [generation][rays, shadow tests], walk list fill and cursor per generation
 constexpr uint32_t WF_MAX_GEN = RT_MAX_ROUNDS + 2;
@@ -375,7 +340,7 @@ int check_args(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam,
 
 // The whole frame, enqueued on `stream`.  Device-resident results: s->color / distance /
 // hit_id / mask (full W*H arrays) and `d_rgb` (owned rows).
-int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const RtRenderConfig& rc, uint8_t* d_rgb,
+int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamera& cc, const RtRenderConfig& rc, uint8_t* d_rgb,
                   bool count_work, hipStream_t stream) {
     const uint32_t W = dim.width, H = dim.height;
     const size_t npix = (size_t)W * H;
@@ -401,7 +366,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
 
     // rows this rank renders: owned row blocks plus the AA halo
     uint32_t key[5] = {W, H, rp.rank, rp.nranks, rp.tile_rows * 2 + (rc.anti_alias ? 1u : 0u)};
-    if (std::memcmp(key, s->rows_key, sizeof key) != 0 || s->rows_host.empty()) {
+    if (std::memcmp(key, w.rows_key, sizeof key) != 0 || w.rows_host.empty() || !w.rows.p) {
         std::vector<uint8_t> need(H, 0);
         for (uint32_t y = 0; y < H; ++y) {
             bool mine = rp.nranks <= 1 || (y / rp.tile_rows) % rp.nranks == rp.rank;
@@ -409,58 +374,82 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
             need[y] = 1;
             if (rc.anti_alias && rp.nranks > 1) { if (y > 0) need[y - 1] = 1; if (y + 1 < H) need[y + 1] = 1; }
         }
-        s->rows_host.clear();
-        for (uint32_t y = 0; y < H; ++y) if (need[y]) s->rows_host.push_back(y);
-        int e = s->rows.ensure(std::max<size_t>(1, s->rows_host.size()) * sizeof(uint32_t));
+        w.rows_host.clear();
+        for (uint32_t y = 0; y < H; ++y) if (need[y]) w.rows_host.push_back(y);
+        int e = w.rows.ensure(std::max<size_t>(1, w.rows_host.size()) * sizeof(uint32_t));
         if (e != RT_OK) return e;
-        if (!s->rows_host.empty()) HIP_TRY(hipMemcpyAsync(s->rows.p, s->rows_host.data(), s->rows_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (!w.rows_host.empty()) HIP_TRY(hipMemcpyAsync(w.rows.p, w.rows_host.data(), w.rows_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));   // rows_host may be rewritten by the next call
-        std::memcpy(s->rows_key, key, sizeof key);
+        std::memcpy(w.rows_key, key, sizeof key);
     }
-    const uint32_t num_rows = (uint32_t)s->rows_host.size();
+    const uint32_t num_rows = (uint32_t)w.rows_host.size();
 
     int e;
-    if ((e = s->color.ensure(npix * 3 * sizeof(double))) != RT_OK) return e;
-    if ((e = s->distance.ensure(npix * sizeof(double))) != RT_OK) return e;
-    if ((e = s->hit_id.ensure(npix * sizeof(uint32_t))) != RT_OK) return e;
-    if ((e = s->mask.ensure(npix)) != RT_OK) return e;
-    if ((e = s->scalars.ensure(SCALAR_BYTES + sizeof(DCounters))) != RT_OK) return e;
-    unsigned int* scalars = static_cast<unsigned int*>(s->scalars.p);
+    if ((e = w.color.ensure(npix * 3 * sizeof(double))) != RT_OK) return e;
+    if ((e = w.distance.ensure(npix * sizeof(double))) != RT_OK) return e;
+    if ((e = w.hit_id.ensure(npix * sizeof(uint32_t))) != RT_OK) return e;
+    if ((e = w.mask.ensure(npix)) != RT_OK) return e;
+    if ((e = w.scalars.ensure(SCALAR_BYTES + sizeof(DCounters))) != RT_OK) return e;
+    unsigned int* scalars = static_cast<unsigned int*>(w.scalars.p);
     unsigned int* aa_count = scalars + SC_AA_COUNT;
-    DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(s->scalars.p) + SCALAR_BYTES);
-    HIP_TRY(hipMemsetAsync(s->scalars.p, 0, SCALAR_BYTES + sizeof(DCounters), stream));
+    DCounters* counters = reinterpret_cast<DCounters*>(static_cast<char*>(w.scalars.p) + SCALAR_BYTES);
+    HIP_TRY(hipMemsetAsync(w.scalars.p, 0, SCALAR_BYTES + sizeof(DCounters), stream));
     // hand-over queues between rounds, one accumulator per sample slot
     const uint32_t queue_cap = (uint32_t)std::min<size_t>(std::max<size_t>(npix * 4, 1u << 22), 1u << 25);
     const size_t acc_slots = npix * std::max(1u, rc.anti_alias ? rc.aa_rays : 1u);
+    const bool aa_pass = rc.anti_alias && W >= 3 && H >= 3 && num_rows > 0;
+    if (aa_pass) {   // worst case every owned interior pixel is flagged
+        const size_t owned_px = (size_t)W * num_rows;
+        if ((e = w.list.ensure(owned_px * sizeof(uint32_t))) != RT_OK) return e;
+        if ((e = w.samples.ensure(owned_px * rc.aa_rays * 3 * sizeof(double))) != RT_OK) return e;
+    }
+    // A workspace over caller-provided memory (the entry point that allocates nothing): one chain of
+    // launches, the BVH walk on at most 128 CUs (its overflow stacks are sized by that), and queues as
+    // large as what the other buffers leave.
+    const bool fixed_mem = w.color.arena != nullptr;
+    const uint32_t walk_cus_max = fixed_mem ? std::min(128u, (uint32_t)s->num_cus) : (uint32_t)s->num_cus;
+    const size_t walk_overflow_bytes = (size_t)(fixed_mem ? 1u : 4u) * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4u;   // per chain: a walk launch with up to 2048 threads per CU
+    const size_t wf_entry_bytes = 2 * (RQ_NF * 8 + RQ_NU * 4) + 2 * (SQ_NF * 8 + SQ_NU * 4) + 2 * (JQ_NF * 8 + JQ_NU * 4) +
+                                  (s->ds.has_background ? CQ_NF * 8 + CQ_NU * 4 : 0) + 2 * sizeof(uint32_t);
     // queue pipeline: s->wf_scale entries per pixel (and queue) of this rank's share, every queue cut into RT_WF_Q sub-queues
     uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)W * num_rows * s->wf_scale, 1u << 20), WF_CAP_MAX);
     if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, (long)WF_CAP_MAX); }   // tests: provoke an overflow
+    if (fixed_mem) {
+        const size_t fixed = acc_slots * (RT_ACC_LIMBS * 8 + 4) + walk_overflow_bytes + WF_SCALAR_BYTES + 16 * 256;   // what is still to come, with alignment slack
+        const size_t left = w.color.arena->capacity > w.color.arena->used + fixed ? w.color.arena->capacity - w.color.arena->used - fixed : 0;
+        wf_cap = (uint32_t)std::min<size_t>(std::min<size_t>(left / wf_entry_bytes, (size_t)W * num_rows * 32), WF_CAP_MAX);
+    }
     wf_cap = (wf_cap / RT_WF_Q) * RT_WF_Q;
     // The pipeline runs recursion_depth + 1 generations out of a scalar block sized for WF_MAX_GEN, and
     // generation 0 (one ray per pixel) must fit the queues: frames beyond either run on the persistent kernel.
-    const bool wavefront = use_wavefront(s->ds.features) && !s->queue_overflowed && rc.recursion_depth + 1 <= WF_MAX_GEN &&
-                           (size_t)W * num_rows <= wf_cap;
-    if (!wavefront) for (auto& q : s->queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
-    {
-        bool fresh = s->acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
-        if ((e = s->acc.ensure(acc_slots * RT_ACC_LIMBS * 8)) != RT_OK) return e;
-        if ((e = s->acc_flags.ensure(acc_slots * 4)) != RT_OK) return e;
-        if (fresh || s->acc_dirty) {
-            HIP_TRY(hipMemsetAsync(s->acc.p, 0, s->acc.bytes, stream));
-            HIP_TRY(hipMemsetAsync(s->acc_flags.p, 0, s->acc_flags.bytes, stream));
-        }
-        s->acc_dirty = true;
+    const bool wavefront = use_wavefront(s->ds.features) && (fixed_mem || !s->queue_overflowed) && rc.recursion_depth + 1 <= WF_MAX_GEN &&
+                           (size_t)W * num_rows <= wf_cap && wf_cap >= RT_WF_Q;
+    if (fixed_mem && !wavefront) {
+        if (!use_wavefront(s->ds.features) || rc.recursion_depth + 1 > WF_MAX_GEN)
+            return fail(RT_ERR_UNSUPPORTED, "this scene / recursion depth needs the persistent-kernel schedule, whose per-lane memory the static scratch array does not hold");
+        return fail(RT_ERR_CAPACITY, "frame workspace exceeds the static scratch array");
     }
-    HIP_TRY(hipMemsetAsync(s->mask.p, 0, npix, stream));
+    if (!wavefront) for (auto& q : w.queue) if ((e = q.ensure((size_t)queue_cap * sizeof(LaneRay))) != RT_OK) return e;
+    {
+        bool fresh = w.acc.bytes < acc_slots * RT_ACC_LIMBS * 8;
+        if ((e = w.acc.ensure(acc_slots * RT_ACC_LIMBS * 8)) != RT_OK) return e;
+        if ((e = w.acc_flags.ensure(acc_slots * 4)) != RT_OK) return e;
+        if (fresh || w.acc_dirty) {
+            HIP_TRY(hipMemsetAsync(w.acc.p, 0, w.acc.bytes, stream));
+            HIP_TRY(hipMemsetAsync(w.acc_flags.p, 0, w.acc_flags.bytes, stream));
+        }
+        w.acc_dirty = true;
+    }
+    HIP_TRY(hipMemsetAsync(w.mask.p, 0, npix, stream));
     if (rp.nranks > 1) {   // rows never rendered by this rank must not look like data (their colour resolves to 0)
-        HIP_TRY(hipMemsetAsync(s->distance.p, 0, npix * sizeof(double), stream));
-        HIP_TRY(hipMemsetAsync(s->hit_id.p, 0xFF, npix * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(w.distance.p, 0, npix * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(w.hit_id.p, 0xFF, npix * sizeof(uint32_t), stream));
     }
 
     // persistent grid: enough waves to fill every CU several times over; each pulls tiles until none are left
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
     const uint32_t max_waves = (uint32_t)s->num_cus * 8;           // two waves per SIMD: all the register file allows
-    if (!wavefront && (e = s->lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
+    if (!wavefront && (e = w.lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
     // Queries per trip.  Depth-first order (one ray per trip) needs at most per_level x depth + spawn + 1
@@ -477,12 +466,12 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         wide_sp_limit = wide <= RT_MAX_STACK ? (uint32_t)(RT_MAX_STACK - wide) : 0u;
     }
     TraceArgs ta{};
-    ta.rows = (const uint32_t*)s->rows.p; ta.num_rows = num_rows;
-    ta.distance = (double*)s->distance.p; ta.hit_id = (uint32_t*)s->hit_id.p;
+    ta.rows = (const uint32_t*)w.rows.p; ta.num_rows = num_rows;
+    ta.distance = (double*)w.distance.p; ta.hit_id = (uint32_t*)w.hit_id.p;
     ta.list = nullptr; ta.count = aa_count; ta.counters = counters; ta.mode = 0;
     ta.refill_min = refill_min();
-    ta.batch = batch; ta.wide_sp_limit = wide_sp_limit; ta.lane_mem = (uint8_t*)s->lane_mem.p;
-    ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)s->acc.p; ta.acc_flags = (uint32_t*)s->acc_flags.p;
+    ta.batch = batch; ta.wide_sp_limit = wide_sp_limit; ta.lane_mem = (uint8_t*)w.lane_mem.p;
+    ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)w.acc.p; ta.acc_flags = (uint32_t*)w.acc_flags.p;
     // Rounds: a launch ends once its work has all been dealt out, and what the lanes still hold is
     // dealt out again by the next one.  A ray handed on is traced in the next round, so a chain of
     // secondary rays advances at least one level per round: recursion_depth + 1 rounds reach every
@@ -496,9 +485,9 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
             ta.next_item = scalars + (mode == 0 ? SC_NEXT0 : SC_NEXT1) + r;
             ta.idle_count = scalars + (mode == 0 ? SC_IDLE0 : SC_IDLE1) + r;
             ta.idle_limit = std::max(1u, (r == 0 ? first_grid : max_waves) * 64u / idle_divisor());
-            ta.in_items = (const LaneRay*)s->queue[r & 1].p;
+            ta.in_items = (const LaneRay*)w.queue[r & 1].p;
             ta.in_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r;
-            ta.out_items = (LaneRay*)s->queue[(r + 1) & 1].p;
+            ta.out_items = (LaneRay*)w.queue[(r + 1) & 1].p;
             ta.out_count = scalars + (mode == 0 ? SC_QUEUE0 : SC_QUEUE1) + r + 1;
             int lrc = launch_trace(s->ds.features, count_work, r == 0 ? first_grid : max_waves, stream, s->ds, rp, ta);
             if (lrc != RT_OK) return lrc;
@@ -514,50 +503,50 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     WfArgs wa{};
     if (wavefront) {
         const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
-        for (auto& b : s->wf_rays) if ((e = b.ensure(n * (RQ_NF * 8 + RQ_NU * 4))) != RT_OK) return e;
-        for (auto& b : s->wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
-        if ((e = s->wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
-        if ((e = s->wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
-        if (s->ds.has_background && (e = s->wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
-        if ((e = s->wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
-        if ((e = s->wf_overflow.ensure((size_t)4 * s->num_cus * 8 * 256 * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4)) != RT_OK) return e;   // per chain: a walk launch with up to 2048 threads per CU
-        if ((e = s->wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
-        HIP_TRY(hipMemsetAsync(s->wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
-        s->wf_cap = (uint32_t)n;
+        for (auto& b : w.wf_rays) if ((e = b.ensure(n * (RQ_NF * 8 + RQ_NU * 4))) != RT_OK) return e;
+        for (auto& b : w.wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
+        if ((e = w.wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
+        if ((e = w.wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
+        if (s->ds.has_background && (e = w.wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
+        if ((e = w.wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
+        if ((e = w.wf_overflow.ensure(walk_overflow_bytes)) != RT_OK) return e;
+        if ((e = w.wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
+        HIP_TRY(hipMemsetAsync(w.wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
+        w.wf_cap = (uint32_t)n;
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
-        wa.rjobs = queue(s->wf_rjobs, n, JQ_NF); wa.sjobs = queue(s->wf_sjobs, n, JQ_NF);
+        wa.rjobs = queue(w.wf_rjobs, n, JQ_NF); wa.sjobs = queue(w.wf_sjobs, n, JQ_NF);
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
-        wa.walk_list = (uint32_t*)s->wf_walk_list.p; wa.walk_overflow = (uint32_t*)s->wf_overflow.p; wa.refill_min = std::getenv("RT_REFILL_MIN") ? refill_min() : 24u; wa.descend_frac = descend_frac();   // (measured: 24 free lanes before the walk kernel refills, 16 in the persistent kernel)
-        wa.contrib = queue(s->wf_contrib, n, CQ_NF);
-        wa.acc = (unsigned long long*)s->acc.p; wa.acc_flags = (uint32_t*)s->acc_flags.p;
-        wa.distance = (double*)s->distance.p; wa.hit_id = (uint32_t*)s->hit_id.p; wa.counters = counters;
+        wa.walk_list = (uint32_t*)w.wf_walk_list.p; wa.walk_overflow = (uint32_t*)w.wf_overflow.p; wa.refill_min = std::getenv("RT_REFILL_MIN") ? refill_min() : 24u; wa.descend_frac = descend_frac();   // (measured: 24 free lanes before the walk kernel refills, 16 in the persistent kernel)
+        wa.contrib = queue(w.wf_contrib, n, CQ_NF);
+        wa.acc = (unsigned long long*)w.acc.p; wa.acc_flags = (uint32_t*)w.acc_flags.p;
+        wa.distance = (double*)w.distance.p; wa.hit_id = (uint32_t*)w.hit_id.p; wa.counters = counters;
         wa.dropped = (unsigned int*)s->wf_sticky.p;
-        wa.rows = (const uint32_t*)s->rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
+        wa.rows = (const uint32_t*)w.rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
         { const char* dbg = std::getenv("RT_WF_DEBUG"); wa.debug = dbg ? (uint32_t)std::atoi(dbg) : 0u; }
     }
     auto run_wavefront = [&](uint32_t mode, double* dst) -> int {
-        unsigned int* ws = (unsigned int*)s->wf_scalars.p + mode * WF_PASS_WORDS;
+        unsigned int* ws = (unsigned int*)w.wf_scalars.p + mode * WF_PASS_WORDS;
         const uint32_t generations = std::min(rc.recursion_depth + 1, WF_MAX_GEN);
         const uint32_t grid = std::max(1u, (uint32_t)s->num_cus * 16 / RT_WF_Q) * RT_WF_Q;   // a whole number of workgroups per sub-queue
         wa.mode = mode;
-        wa.list = (const uint32_t*)s->list.p;
+        wa.list = (const uint32_t*)w.list.p;
         // generation 0 into queue set 0
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
         const size_t n = wa.cap;
-        wa.out_rays = queue(s->wf_rays[0], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
+        wa.out_rays = queue(w.wf_rays[0], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
         hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
         HIP_TRY(hipGetLastError());
-        const uint32_t chains = wf_chains((size_t)W * num_rows);
+        const uint32_t chains = fixed_mem ? 1u : wf_chains((size_t)W * num_rows);
         uint32_t* const overflow0 = wa.walk_overflow;
         if (chains > 1) {                                             // the other chains start once generation 0 is in the queues
             HIP_TRY(hipEventRecord(s->chain_fork, stream));
             for (uint32_t c = 1; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(s->chain_stream[c - 1], s->chain_fork, 0));
         }
         for (uint32_t g = 0; g < generations; ++g) {
-            wa.rays = queue(s->wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(s->wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
-            wa.out_rays = queue(s->wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(s->wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
+            wa.rays = queue(w.wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(w.wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
+            wa.out_rays = queue(w.wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
             wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g;
-            wa.hit_count = (unsigned int*)s->wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
+            wa.hit_count = (unsigned int*)w.wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             for (uint32_t c = 0; c < chains; ++c) {
                 hipStream_t cs = c == 0 ? stream : s->chain_stream[c - 1];
                 // CUs for the chain's walk kernel (one workgroup fills a CU's LDS).  Two chains: three
@@ -566,10 +555,10 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
                 // 56.4 ms at all CUs); four chains: a quarter each.
                 static const long walk_cus = [] { const char* e = std::getenv("RT_WF_WALK_CUS"); return e ? std::atol(e) : 0L; }();
                 const uint32_t share = chains == 2 ? (uint32_t)s->num_cus * 3u / 4u : (uint32_t)s->num_cus / chains;
-                const uint32_t cus = std::max(1u, walk_cus > 0 && chains > 1 ? (uint32_t)std::min<long>(walk_cus, s->num_cus) : share);
+                const uint32_t cus = std::min(walk_cus_max, std::max(1u, walk_cus > 0 && chains > 1 ? (uint32_t)std::min<long>(walk_cus, s->num_cus) : share));
                 wa.sq_count = RT_WF_Q / chains; wa.sq_base = c * wa.sq_count;
                 wa.walk_next = ws + WF_WALK_NEXT + RT_WF_Q * g + c;   // (a cursor per chain)
-                wa.walk_overflow = overflow0 + (size_t)c * cus * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK);   // (a walk launch has at most 2048 threads per CU)
+                wa.walk_overflow = overflow0 + (size_t)c * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK);   // (a walk launch has at most 2048 threads per CU)
                 const uint32_t cgrid = grid / chains;
                 int lrc = wf_launch(0, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
@@ -600,30 +589,26 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
         return RT_OK;
     };
     if (num_rows > 0) {
-        int lrc = wavefront ? run_wavefront(0, (double*)s->color.p) : run_rounds(0, std::min(tiles, max_waves), (double*)s->color.p);
+        int lrc = wavefront ? run_wavefront(0, (double*)w.color.p) : run_rounds(0, std::min(tiles, max_waves), (double*)w.color.p);
         if (lrc != RT_OK) return lrc;
     }
     HIP_TRY(hipEventRecord(s->ev[1], stream));
-    if (rc.anti_alias && W >= 3 && H >= 3 && num_rows > 0) {
-        // worst case every owned interior pixel is flagged
-        size_t owned_px = (size_t)W * num_rows;
-        if ((e = s->list.ensure(owned_px * sizeof(uint32_t))) != RT_OK) return e;
-        if ((e = s->samples.ensure(owned_px * rc.aa_rays * 3 * sizeof(double))) != RT_OK) return e;
+    if (aa_pass) {
         uint32_t blocks = (uint32_t)((npix + 255) / 256);
-        hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, (const double*)s->distance.p,
-                           (uint32_t*)s->list.p, aa_count, (uint8_t*)s->mask.p);
+        hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)w.color.p, (const double*)w.distance.p,
+                           (uint32_t*)w.list.p, aa_count, (uint8_t*)w.mask.p);
         HIP_TRY(hipGetLastError());
-        ta.list = (const uint32_t*)s->list.p;
-        int lrc = wavefront ? run_wavefront(1, (double*)s->samples.p) : run_rounds(1, max_waves, (double*)s->samples.p);
+        ta.list = (const uint32_t*)w.list.p;
+        int lrc = wavefront ? run_wavefront(1, (double*)w.samples.p) : run_rounds(1, max_waves, (double*)w.samples.p);
         if (lrc != RT_OK) return lrc;
-        hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)s->list.p, aa_count,
-                           (const double*)s->samples.p, (double*)s->color.p, (double*)s->distance.p);
+        hipLaunchKernelGGL(k_aa_combine, dim3(1024), dim3(256), 0, stream, rp, (const uint32_t*)w.list.p, aa_count,
+                           (const double*)w.samples.p, (double*)w.color.p, (double*)w.distance.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev[2], stream));
     if (d_rgb) {
         uint32_t blocks = (uint32_t)((npix + 255) / 256);
-        hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, stream, rp, (const double*)s->color.p, d_rgb);
+        hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, stream, rp, (const double*)w.color.p, d_rgb);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev[3], stream));
@@ -631,7 +616,7 @@ int enqueue_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cc, const R
     if (wavefront) HIP_TRY(hipMemcpyAsync(s->h_dropped, s->wf_sticky.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(s->ev_done, stream));
     s->timed = true;
-    s->acc_dirty = false;
+    w.acc_dirty = false;
     return RT_OK;
 }
 
@@ -642,6 +627,7 @@ bool note_drops(RtScene* s) {
     const unsigned int now = *s->h_dropped;
     if (now == s->dropped_seen) return false;
     s->dropped_seen = now;
+    if (s->last_noalloc) return true;
     if (s->wf_scale < 32 && !std::getenv("RT_WF_CAP")) s->wf_scale *= 2;
     else s->queue_overflowed = true;
     return true;
@@ -651,8 +637,9 @@ bool note_drops(RtScene* s) {
 int render_complete_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cam, const RtRenderConfig& cfg, uint8_t* d_rgb,
                           bool count, hipStream_t stream) {
     for (int attempt = 0; attempt < 8; ++attempt) {
-        int rc = enqueue_frame(s, dim, cam, cfg, d_rgb, count, stream);
+        int rc = enqueue_frame(s, s->ws, dim, cam, cfg, d_rgb, count, stream);
         if (rc != RT_OK) return rc;
+        s->last_noalloc = false;
         HIP_TRY(hipStreamSynchronize(stream));
         if (!s->last_used_queues || !note_drops(s)) { s->dropped_reported = s->dropped_seen; return RT_OK; }
     }
@@ -688,19 +675,20 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
     // an earlier asynchronous frame that lost rays (known once it has finished): larger queues from now on
     if (s->last_used_queues) (void)note_drops(s);
     if (count) rc = render_complete_frame(s, *dim, *cam, *cfg, d_rgb_out, true, stream);   // this variant of the call synchronises anyway
-    else rc = enqueue_frame(s, *dim, *cam, *cfg, d_rgb_out, false, stream);
+    else rc = enqueue_frame(s, s->ws, *dim, *cam, *cfg, d_rgb_out, false, stream);
     if (rc != RT_OK) return rc;
+    s->last_noalloc = false;
     if (d_aux) {
         const size_t npix = (size_t)dim->width * dim->height;
-        if (d_aux->color) HIP_TRY(hipMemcpyAsync(d_aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        if (d_aux->distance) HIP_TRY(hipMemcpyAsync(d_aux->distance, s->distance.p, npix * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        if (d_aux->hit_id) HIP_TRY(hipMemcpyAsync(d_aux->hit_id, s->hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-        if (d_aux->aa_mask) HIP_TRY(hipMemcpyAsync(d_aux->aa_mask, s->mask.p, npix, hipMemcpyDeviceToDevice, stream));
+        if (d_aux->color) HIP_TRY(hipMemcpyAsync(d_aux->color, s->ws.color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->distance) HIP_TRY(hipMemcpyAsync(d_aux->distance, s->ws.distance.p, npix * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->hit_id) HIP_TRY(hipMemcpyAsync(d_aux->hit_id, s->ws.hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        if (d_aux->aa_mask) HIP_TRY(hipMemcpyAsync(d_aux->aa_mask, s->ws.mask.p, npix, hipMemcpyDeviceToDevice, stream));
         if (count) {   // counters are host-visible results: this variant of the call synchronises
             DCounters c{};
             unsigned int aa = 0;
-            HIP_TRY(hipMemcpyAsync(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&c, static_cast<char*>(s->ws.scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&aa, static_cast<char*>(s->ws.scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
             fill_counters(d_aux->counters, c);
@@ -755,29 +743,29 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
         HIP_TRY(hipSetDevice(s->device));
         uint32_t rows_cap = rt_owned_rows_capacity(dim->height, cfg->nranks, cfg->tile_rows);
         size_t rgb_bytes = (size_t)rows_cap * dim->width * 3;
-        int e = s->rgb_full.ensure(rgb_bytes);
+        int e = s->ws.rgb_full.ensure(rgb_bytes);
         if (e != RT_OK) return e;
-        HIP_TRY(hipMemsetAsync(s->rgb_full.p, 0, rgb_bytes, nullptr));
+        HIP_TRY(hipMemsetAsync(s->ws.rgb_full.p, 0, rgb_bytes, nullptr));
         bool count = aux && aux->count_work;
         if (s->last_used_queues) (void)note_drops(s);
-        rc = render_complete_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->rgb_full.p), count, nullptr);
+        rc = render_complete_frame(s, *dim, *cam, *cfg, static_cast<uint8_t*>(s->ws.rgb_full.p), count, nullptr);
         if (rc != RT_OK) return rc;
-        HIP_TRY(hipMemcpy(rgb_out, s->rgb_full.p, rgb_bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rgb_out, s->ws.rgb_full.p, rgb_bytes, hipMemcpyDeviceToHost));
         if (aux) {
-            if (aux->color) HIP_TRY(hipMemcpy(aux->color, s->color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
-            if (aux->distance) HIP_TRY(hipMemcpy(aux->distance, s->distance.p, npix * sizeof(double), hipMemcpyDeviceToHost));
-            if (aux->hit_id) HIP_TRY(hipMemcpy(aux->hit_id, s->hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            if (aux->aa_mask) HIP_TRY(hipMemcpy(aux->aa_mask, s->mask.p, npix, hipMemcpyDeviceToHost));
+            if (aux->color) HIP_TRY(hipMemcpy(aux->color, s->ws.color.p, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
+            if (aux->distance) HIP_TRY(hipMemcpy(aux->distance, s->ws.distance.p, npix * sizeof(double), hipMemcpyDeviceToHost));
+            if (aux->hit_id) HIP_TRY(hipMemcpy(aux->hit_id, s->ws.hit_id.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (aux->aa_mask) HIP_TRY(hipMemcpy(aux->aa_mask, s->ws.mask.p, npix, hipMemcpyDeviceToHost));
             DCounters c{};
             unsigned int aa = 0;
-            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->ws.scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->ws.scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
             fill_counters(aux->counters, c);
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
             DCounters c{};
-            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->ws.scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
             const char* names[8] = {"trips", "phase A jobs", "walk descend", "walk refill", "walk leaf", "phase B rays", "", ""};
             for (int i = 0; i < 6; ++i)
                 std::fprintf(stderr, "[rt] %-14s wave trips %12llu  lanes/trip %5.1f\n", names[i], c.prof[2 * i], c.prof[2 * i] ? (double)c.prof[2 * i + 1] / (double)c.prof[2 * i] : 0.0);
@@ -787,15 +775,15 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work && s->last_used_queues) {   // where the shade kernel's waves spend their time
             DCounters c{};
-            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->ws.scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
             const double it = (double)c.prof[PF_TRIPS] + 1e-30;
             std::fprintf(stderr, "[rt] shade: %llu wave trips, %.1f hits each; cycles per trip: list+instance %.0f, reservation %.0f, ray+world hit %.0f, material %.0f, holes %.0f, accumulation %.0f; start-up %llu\n",
                          c.prof[PF_TRIPS], (double)c.prof[PF_TRIP_LANES] / it, c.prof[PF_A_ITERS] / it, c.prof[PF_A_LANES] / it, c.prof[PF_B_ITERS] / it,
                          c.prof[PF_B_LANES] / it, c.prof[PF_CYC_A] / it, c.prof[PF_CYC_T] / it, c.prof[PF_CYC_FETCH]);
         }
-        if (std::getenv("RT_DEBUG_ROUNDS") && s->wf_scalars.p && s->last_used_queues) {   // queue fill per generation
+        if (std::getenv("RT_DEBUG_ROUNDS") && s->ws.wf_scalars.p && s->last_used_queues) {   // queue fill per generation
             std::vector<unsigned int> ws(WF_SCALAR_BYTES / 4);
-            HIP_TRY(hipMemcpy(ws.data(), s->wf_scalars.p, WF_SCALAR_BYTES, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ws.data(), s->ws.wf_scalars.p, WF_SCALAR_BYTES, hipMemcpyDeviceToHost));
             for (int pass = 0; pass < 2; ++pass) {
                 std::fprintf(stderr, "[rt] pass %d rays+shadow tests per generation (largest sub-queue):", pass);
                 for (uint32_t g = 0; g <= RT_MAX_ROUNDS; ++g) {
@@ -809,11 +797,11 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
                 }
                 std::fprintf(stderr, "\n");
             }
-            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->wf_cap / RT_WF_Q), *s->h_dropped);
+            std::fprintf(stderr, "[rt] sub-queue capacity %u, dropped %u\n", (unsigned)(s->ws.wf_cap / RT_WF_Q), *s->h_dropped);
         }
         if (std::getenv("RT_DEBUG_ROUNDS")) {   // how many rays each round handed on
             unsigned int sc[SCALAR_BYTES / 4];
-            HIP_TRY(hipMemcpy(sc, s->scalars.p, SCALAR_BYTES, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc, s->ws.scalars.p, SCALAR_BYTES, hipMemcpyDeviceToHost));
             std::fprintf(stderr, "[rt] queue pass1:");
             for (uint32_t r = 1; r <= RT_MAX_ROUNDS && sc[SC_QUEUE0 + r]; ++r) std::fprintf(stderr, " %u", sc[SC_QUEUE0 + r]);
             std::fprintf(stderr, "\n[rt] queue aa:");

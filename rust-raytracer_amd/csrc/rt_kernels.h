@@ -423,6 +423,7 @@ k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
 }
 
 // ------------------------------------------------------------------ accumulators -> f64
+#ifdef RT_FRAME_KERNELS   // (the kernels from here on are not templates: compiled once, by the file that launches them)
 // One accumulator per sample slot; dst is the colour buffer (pass 1) or the AA sample buffer.
 // Leaves every accumulator zero again.
 __global__ void __launch_bounds__(256)
@@ -514,3 +515,4 @@ k_encode(DRenderParams rp, const double* __restrict__ color, uint8_t* __restrict
     rgb[oi + 1] = encode_channel(color[3 * ci + 1]);
     rgb[oi + 2] = encode_channel(color[3 * ci + 2]);
 }
+#endif  // RT_FRAME_KERNELS

@@ -1,0 +1,75 @@
+// rt_variants.h — the feature variants of the big kernels, one translation unit each.
+//
+// The trace kernel (rt_kernels.h) and the queue pipeline's analytic / settle / shade kernels
+// (rt_wavefront.h) are compiled for a handful of feature sets; a scene runs on the smallest one that
+// covers what it contains (fewer registers and less scratch than the all-features build).  Every
+// variant lives in a source file of its own under variants/ (they compile side by side); the frame
+// driver in rt_api.hip only sees the launch functions declared here.
+#pragma once
+#include "rt_wavefront.h"
+
+constexpr uint32_t V_MESH = RTF_MESH;                                         // rooms + meshes, point lights (glass_monkey)
+constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
+constexpr uint32_t V_BALLS = RTF_WRAP | RTF_IMAGES | RTF_TLAS;                // one-way spheres, skybox, maps, many instances (many_balls)
+constexpr uint32_t V_CSG = RTF_CSG | RTF_FACED | RTF_IMAGES;                  // composite shapes under a skybox
+constexpr uint32_t V_AREA_MESH = V_AREA | RTF_MESH;                           // square light + mesh + maps (monkey_1..3)
+constexpr uint32_t V_EVERYTHING = RTF_ALL | RTF_TLAS;
+constexpr uint32_t V_NO_INLINE = (RTF_ALL | RTF_TLAS) & ~RTF_INLINE_LIGHTS;
+
+// persistent trace kernel
+#define RT_TRACE_VARIANTS(X) \
+    X(plain, 0u) X(mesh_lds, V_MESH | RTF_LDS_BVH) X(mesh, V_MESH) X(balls, V_BALLS) X(area, V_AREA) \
+    X(area_mesh_lds, V_AREA_MESH | RTF_LDS_BVH) X(area_mesh, V_AREA_MESH) X(csg, V_CSG) X(everything, V_EVERYTHING)
+// queue pipeline (no inline lights there)
+#define RT_WF_VARIANTS(X) X(plain, 0u) X(mesh, V_MESH) X(balls, V_BALLS) X(csg, V_CSG) X(everything, V_NO_INLINE)
+
+struct LaunchStatus {             // hipSuccess, or the failing call
+    hipError_t code;
+    const char* what;
+};
+
+#define RT_DECLARE_TRACE(name, F) \
+    LaunchStatus rt_launch_trace_##name(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta);
+RT_TRACE_VARIANTS(RT_DECLARE_TRACE)
+#undef RT_DECLARE_TRACE
+// which: 0 analytic, 1 shade, 2 settle
+#define RT_DECLARE_WF(name, F) \
+    LaunchStatus rt_launch_wf_##name(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa);
+RT_WF_VARIANTS(RT_DECLARE_WF)
+#undef RT_DECLARE_WF
+LaunchStatus rt_launch_wf_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa);   // num_cus: the chain's share of the CUs
+
+// ---- bodies, instantiated by the variant files only
+template <uint32_t F>
+LaunchStatus launch_trace_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
+    uint32_t block = 64, lds = 0;
+    if (F & RTF_LDS_BVH) { block = 512; grid = grid / 8 > 1u ? grid / 8 : 1u; }   // one 512-thread workgroup per CU, the BVH blob in its LDS
+    if (F & RTF_MESH) lds = RT_LDS_FIXED_BYTES(block) + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // walk stacks, job lists (+ blob)
+    if (lds > 48u * 1024u) {
+        auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return {ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"};
+    }
+    if (count) hipLaunchKernelGGL((k_trace<F, true>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
+    else hipLaunchKernelGGL((k_trace<F, false>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
+    return {hipGetLastError(), "k_trace launch"};
+}
+
+template <uint32_t F>
+LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
+    const bool hot = ds.hot_bytes > 0;                                 // the scene's small tables fit into LDS
+    const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
+    uint32_t lds = tables;
+    if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
+    if (which == 2) lds = 4u * 640u * 8u;
+    const void* fn;
+    if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true> : (const void*)k_wf_analytic<F, false, true>)
+                             : (count ? (const void*)k_wf_analytic<F, true, false> : (const void*)k_wf_analytic<F, false, false>);
+    else if (which == 1) fn = hot ? (count ? (const void*)k_wf_shade<F, true, true> : (const void*)k_wf_shade<F, false, true>)
+                                  : (count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>);
+    else fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
+    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void* params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
+    (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);
+    return {hipGetLastError(), "queue-pipeline kernel launch"};
+}

@@ -159,6 +159,7 @@ RT_DEV void wf_flush(DCounters* g, const Work<COUNT>& wk, unsigned long long cam
 }
 
 // ------------------------------------------------------------------ generation 0
+#ifdef RT_FRAME_KERNELS   // (not templates: compiled once, by the file that launches them)
 // Pass 1: one camera ray per pixel of the rows this rank renders (src/render.rs:163-170).
 // AA resolve: aa_rays jittered camera rays per flagged pixel (src/render.rs:259-299).
 __global__ void __launch_bounds__(256)
@@ -210,6 +211,8 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
         r.U(a.cap, RQ_SLOT, e) = slot; r.U(a.cap, RQ_FLAGS, e) = a.mode == 0 ? 3u : 2u;
     }
 }
+
+#endif  // RT_FRAME_KERNELS
 
 // ------------------------------------------------------------------ analytic phase
 // One thread per queue entry: the sub-queue's rays first, then its shadow tests.
@@ -732,6 +735,7 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
 }
 
 // ------------------------------------------------------------------ accumulation of the analytic phase's terms
+#ifdef RT_FRAME_KERNELS
 // Sky-box scenes only: the background seen by rays that failed the cast_ray gate (k_wf_analytic).
 // One thread per (ray, limb): the nine limbs of one sample are adjacent words.
 __global__ void __launch_bounds__(256)
@@ -761,3 +765,4 @@ k_wf_accumulate(WfArgs a) {
         if (l != 0.0) atomicAdd(a.acc + (size_t)slot * RT_ACC_LIMBS + limb, (unsigned long long)(long long)l);
     }
 }
+#endif  // RT_FRAME_KERNELS

@@ -1,0 +1,21 @@
+// The queue pipeline's BVH walk kernel (k_wf_walk): LDS-resident and global-memory BVH.
+#include "../rt_variants.h"
+LaunchStatus rt_launch_wf_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa) {
+    const bool lds_bvh = ds.lds_blob_bytes != 0;
+    const uint32_t block = lds_bvh ? 1024u : 256u, grid = lds_bvh ? num_cus : num_cus * 8u;
+    const uint32_t lds = RT_WF_WALK_FIXED_BYTES(block) + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
+    const void* fn = lds_bvh ? (count ? (const void*)k_wf_walk<true, true> : (const void*)k_wf_walk<true, false>)
+                             : (count ? (const void*)k_wf_walk<false, true> : (const void*)k_wf_walk<false, false>);
+    if (lds > 48u * 1024u) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return {ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"};
+    }
+    if (lds_bvh) {
+        if (count) hipLaunchKernelGGL((k_wf_walk<true, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
+        else hipLaunchKernelGGL((k_wf_walk<true, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
+    } else {
+        if (count) hipLaunchKernelGGL((k_wf_walk<false, true>), dim3(grid), dim3(block), lds, stream, ds, wa);
+        else hipLaunchKernelGGL((k_wf_walk<false, false>), dim3(grid), dim3(block), lds, stream, ds, wa);
+    }
+    return {hipGetLastError(), "k_wf_walk launch"};
+}
