@@ -287,6 +287,25 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
  * which cannot overflow) by then.  The reference has no counterpart: its recursion cannot lose rays. */
 int rt_frame_status(const RtScene* scene, uint64_t* dropped);
 
+/* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  (No counterpart in the reference.)  It performs no
+ * hipMalloc / hipFree: everything a frame needs beyond `d_rgb_out` lives in one static device array
+ * of RT_NOALLOC_SCRATCH_BYTES that each GPU holds from the first rt_scene_create on it until the
+ * process ends.  Limits: width * height <= RT_NOALLOC_MAX_PIXELS (else RT_ERR_CAPACITY; the AA
+ * buffers for aa_rays > 5 can also exceed the array), scenes and recursion depths that run on the
+ * queue pipeline (no square / directional lights: RT_ERR_UNSUPPORTED otherwise), no aux outputs.
+ * The ray queues get what the array leaves after the image-sized buffers (at the largest frame
+ * about 13 entries per pixel; rt_render_device starts with 8 and at least 2^20) and cannot grow:
+ * pair the call with rt_frame_status, which returns RT_ERR_CAPACITY for a frame that outgrew them.
+ * Larger frames: rt_render_device.
+ * All calls on one GPU — on whichever scene — share that GPU's array: calls that overlap on one
+ * GPU (two streams, two host threads with different scenes) race.  Calls issued one after the other
+ * on one stream are safe. */
+#define RT_NOALLOC_SCRATCH_BYTES (256u << 20)
+#define RT_NOALLOC_MAX_PIXELS 32768u
+int rt_render_device_noalloc(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam,
+                             const RtRenderConfig* cfg, uint8_t* d_rgb_out, void* hip_stream);
+
 /* ceil(ceil(H/tile_rows)/nranks)*tile_rows: rows of the compact per-rank buffer. */
 uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_rows);
 

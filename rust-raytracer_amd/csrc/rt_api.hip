@@ -18,6 +18,11 @@
 #define RT_FRAME_KERNELS   // this file holds the small per-frame kernels (generation 0, resolve, AA, encode)
 #include "rt_variants.h"
 
+// Workspace of rt_render_device_noalloc: every buffer a frame needs beyond its inputs and outputs
+// (image-sized intermediates, accumulators, ray queues, walk stacks) is carved out of this array.
+// Each GPU the library runs on holds its own copy at its own address until the process ends.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_error;
@@ -56,6 +61,21 @@ struct DeviceBuf {
     }
     void release() { if (p && !arena) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
+
+// Device address of `scratch` on each GPU (in host code the array's name is only a handle): looked up
+// once per device, with that device current, when the first scene is created on it.
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64] = {};
+int scratch_lookup(int device) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (device < 0 || device >= 64) return fail(RT_ERR_INVALID_ARG, "device index out of range");
+    if (g_scratch_ptr[device]) return RT_OK;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned no address");
+    g_scratch_ptr[device] = ptr;
+    return RT_OK;
+}
 
 template <class T>
 int upload(const std::vector<T>& v, std::vector<void*>& owned, const T** out) {
@@ -162,6 +182,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         return fail(RT_ERR_INVALID_ARG, e.what());
     }
     HIP_TRY(hipSetDevice(device));
+    { int sr = scratch_lookup(device); if (sr != RT_OK) return sr; }
     RtScene* s = new (std::nothrow) RtScene();
     if (!s) return fail(RT_ERR_DEVICE, "out of host memory");
     s->device = device;
@@ -694,6 +715,30 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
             fill_counters(d_aux->counters, c);
         }
     }
+    return RT_OK;
+}
+
+int rt_render_device_noalloc(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, const RtRenderConfig* cfg,
+                             uint8_t* d_rgb_out, void* hip_stream) {
+    int rc = check_args(scene, dim, cam, cfg);
+    if (rc != RT_OK) return rc;
+    if (!d_rgb_out) return fail(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: d_rgb_out is null");
+    if ((uint64_t)dim->width * dim->height > RT_NOALLOC_MAX_PIXELS)
+        return fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: frame larger than RT_NOALLOC_MAX_PIXELS (" + std::to_string(RT_NOALLOC_MAX_PIXELS) + " pixels)");
+    RtScene* s = const_cast<RtScene*>(scene);
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    void* base = nullptr;
+    { std::lock_guard<std::mutex> gl(g_scratch_mu); base = g_scratch_ptr[s->device]; }
+    if (!base) return fail(RT_ERR_DEVICE, "rt_render_device_noalloc: the scratch array of this device was never looked up");
+    if (s->last_used_queues) (void)note_drops(s);
+    Arena arena;
+    arena.base = static_cast<uint8_t*>(base); arena.capacity = RT_NOALLOC_SCRATCH_BYTES; arena.used = 0;
+    Workspace w;                         // every buffer of the frame: bump-allocated in the arena, all of it re-initialised by the frame
+    w.use(&arena);
+    rc = enqueue_frame(s, w, *dim, *cam, *cfg, d_rgb_out, false, static_cast<hipStream_t>(hip_stream));
+    if (rc != RT_OK) return rc;
+    s->last_noalloc = true;
     return RT_OK;
 }
 

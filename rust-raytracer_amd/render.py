@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")   # RT_AMD_LIB: another build of the same library (kernel tuning experiments)
 
 EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
-           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status"]
+           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status", "rt_render_device_noalloc"]
 
 _lib = None
 
@@ -46,6 +46,9 @@ def hip_lib():
         lib.rt_owned_rows_capacity.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.rt_last_timings.restype = C.c_int
         lib.rt_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.rt_render_device_noalloc.restype = C.c_int
+        lib.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RtImageDim), C.POINTER(RtCamera), C.POINTER(RtRenderConfig),
+                                                 C.c_void_p, C.c_void_p]
         lib.rt_frame_status.restype = C.c_int
         lib.rt_frame_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = lib
@@ -101,6 +104,11 @@ class DeviceScene:
         _check(lib.rt_render_device(self._handle, C.byref(dim), C.byref(cam), C.byref(cfg), C.c_void_p(d_rgb_ptr),
                                     C.byref(d_aux) if d_aux is not None else None,
                                     C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def render_device_noalloc(self, dim, cam, cfg, d_rgb_ptr, stream_ptr=None):
+        """rt_render_device_noalloc: like render_device, workspace in the library's static device array."""
+        _check(hip_lib().rt_render_device_noalloc(self._handle, C.byref(dim), C.byref(cam), C.byref(cfg), C.c_void_p(d_rgb_ptr),
+                                                  C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def last_timings(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
