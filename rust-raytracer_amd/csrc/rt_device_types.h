@@ -113,6 +113,7 @@ struct DMesh {
     uint32_t normal_off, uv_off;   // into mesh_normals (3/vertex) and mesh_uvs (2/vertex)
     uint32_t num_normals, num_uvs;
     double lo[3], hi[3];
+    double max_abs;            // largest |coordinate| of any node box (bounds the rounding error of the f32 box test)
 };
 
 enum DCsgKind { DC_BASE = 0, DC_SUBTRACT, DC_AND, DC_OR, DC_XOR, DC_MULTI_AND };

@@ -245,6 +245,9 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     dm.tri_off = (uint32_t)fs.mesh_tris.size();
     dm.num_tris = m.num_faces;
     put(dm.lo, bn[0].lo - V3{pad, pad, pad}); put(dm.hi, bn[0].hi + V3{pad, pad, pad});
+    dm.max_abs = 0.0;
+    for (int k = 0; k < 3; ++k) dm.max_abs = std::max(dm.max_abs, std::max(std::fabs(dm.lo[k]), std::fabs(dm.hi[k])));
+    dm.max_abs *= 1.0 + 1e-6;   // (the f32 copies of the boxes are rounded outward by up to 2^-23 of their value)
     // triangles in BVH order; derived values as Mesh::from_path computes them (mesh.rs:396-404)
     for (uint32_t i = 0; i < m.num_faces; ++i) {
         uint32_t f = bt[i].face;

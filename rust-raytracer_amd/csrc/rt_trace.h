@@ -290,16 +290,50 @@ RT_DEV bool slab(const double* lo, const double* hi, d3 o, d3 inv, double tmax, 
     return tn <= tf && tf >= 0.0 && tn <= tmax;
 }
 
-RT_DEV bool slab_f32(const float* lo, const float* hi, d3 o, d3 inv, double tmax, double& tnear) {
-    double t0 = ((double)lo[0] - o.x) * inv.x, t1 = ((double)hi[0] - o.x) * inv.x;
-    double tn = fmin(t0, t1), tf = fmax(t0, t1);
-    t0 = ((double)lo[1] - o.y) * inv.y; t1 = ((double)hi[1] - o.y) * inv.y;
-    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
-    t0 = ((double)lo[2] - o.z) * inv.z; t1 = ((double)hi[2] - o.z) * inv.z;
-    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
-    tnear = tn;
-    return tn <= tf && tf >= 0.0 && tn <= tmax;
+// ---- the box test of the f32 node records (LBvhNode), in f32
+// A box test only culls: it may accept a box the ray misses, never reject one it hits.  That leaves
+// room for cheaper arithmetic than the f64 slab test above, as long as every rounding error is
+// covered: per axis the entry and exit parameters are computed as
+//     t_near = P_near * inv + a_near,   t_far = P_far * inv + a_far        (one fused f32 operation each)
+// with P_near / P_far the box's lo or hi plane by the sign of the direction, inv = 1/d rounded to
+// f32, a_near = -(o/d) - c and a_far = -(o/d) + c rounded to f32, and c = (|o| + M) |1/d| 2^-21 where
+// M bounds |P| over the whole tree.  The three roundings (inv, a, the fused operation) each
+// contribute at most (|P| + |o|) |1/d| 2^-24 (+ c 2^-24 for a), together less than c/2, so
+// [t_near, t_far] contains the exact interval.  In space the slack is (|o| + M) 2^-21, far below the
+// size of any box.  Directions with a zero component give infinities / NaNs; fminf / fmaxf drop
+// NaNs, which leaves that axis unconstrained (accepting, never rejecting).
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+struct Slab32 {
+    rt_f2 inv[3];          // (1/d, 1/d) per axis
+    rt_f2 a[3];            // (a_near, a_far) per axis
+    bool neg[3];           // 1/d < 0: the hi plane is the near one
+};
+RT_DEV Slab32 slab32_setup(d3 o, d3 inv, double max_abs) {
+    Slab32 r;
+    const double ov[3] = {o.x, o.y, o.z}, iv[3] = {inv.x, inv.y, inv.z};
+    for (int k = 0; k < 3; ++k) {
+        const double oi = ov[k] * iv[k];
+        const double c = (fabs(ov[k]) + max_abs) * fabs(iv[k]) * 0x1p-21;
+        const float i32 = (float)iv[k];
+        r.inv[k] = rt_f2{i32, i32};
+        r.a[k] = rt_f2{(float)(-oi - c), (float)(-oi + c)};
+        r.neg[k] = iv[k] < 0.0;
+    }
+    return r;
 }
+RT_DEV float slab32_limit(double tmax) {            // tmax as f32, rounded up
+    const float t = (float)tmax;
+    return t + fabsf(t) * 0x1p-22f;
+}
+RT_DEV bool slab32_box(const float* lo, const float* hi, const Slab32& r, float tmax, float& tnear) {
+    const rt_f2 tx = __builtin_elementwise_fma(r.neg[0] ? rt_f2{hi[0], lo[0]} : rt_f2{lo[0], hi[0]}, r.inv[0], r.a[0]);
+    const rt_f2 ty = __builtin_elementwise_fma(r.neg[1] ? rt_f2{hi[1], lo[1]} : rt_f2{lo[1], hi[1]}, r.inv[1], r.a[1]);
+    const rt_f2 tz = __builtin_elementwise_fma(r.neg[2] ? rt_f2{hi[2], lo[2]} : rt_f2{lo[2], hi[2]}, r.inv[2], r.a[2]);
+    const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x), tf = fminf(fminf(tx.y, ty.y), tz.y);
+    tnear = tn;
+    return tn <= tf && tf >= 0.0f && tn <= tmax;
+}
+
 // LDS copies of a node / a triangle, read 16 bytes at a time (the blob and the records' offsets in
 // it are multiples of 16 bytes; left to itself the compiler reads them word by word).
 RT_DEV LBvhNode lds_node(const LBvhNode* p) {
@@ -360,25 +394,29 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
     uint32_t cur = 0;
     bool found = false;
     double best = tmax;
+    Slab32 s32 = slab32_setup(r.o, inv, m.max_abs);          // (LDS walk: the f32 box test)
+    float best32 = slab32_limit(best);
     while (cur != RT_WALK_DONE) {
         while (!(cur & 0x80000000u)) {                         // descend to a leaf
-            double tn0, tn1;
-            bool h0, h1;
+            bool h0, h1, swap;
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
             if (LDS) {
+                float tn0, tn1;
                 const LBvhNode n = lds_node(lnodes + cur);
-                h0 = slab_f32(n.lo[0], n.hi[0], r.o, inv, best, tn0);
-                h1 = slab_f32(n.lo[1], n.hi[1], r.o, inv, best, tn1);
+                h0 = slab32_box(n.lo[0], n.hi[0], s32, best32, tn0);
+                h1 = slab32_box(n.lo[1], n.hi[1], s32, best32, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             } else {
+                double tn0, tn1;
                 const DBvhNode& n = gnodes[cur];
                 h0 = slab(n.lo[0], n.hi[0], r.o, inv, best, tn0);
                 h1 = slab(n.lo[1], n.hi[1], r.o, inv, best, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             }
             if (h0 && h1) {
-                bool swap = tn1 < tn0;
                 cur = swap ? c1 : c0;
                 if (sp < RT_BVH_STACK) stack[sp++] = swap ? c0 : c1;
             } else if (h0) cur = c0;
@@ -396,6 +434,7 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
                     if (inclusive ? t <= tmax : t < tmax) { found = true; }
                 } else if (t < best) {
                     best = t; tri_out = base + i; found = true;
+                    if (LDS) best32 = slab32_limit(best);
                 }
             }
         }
@@ -448,6 +487,8 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
     uint32_t qinst = 0, qfound = 0, qca = 0;
     LRay lr; lr.o = mk3(0.0, 0.0, 0.0); lr.d = lr.o;
     d3 inv = lr.o;
+    Slab32 s32 = slab32_setup(lr.o, lr.o, 0.0);                      // (LDS walk: the f32 box test)
+    float best32 = 0.0f;
     double best = 0.0, tmax = 0.0, inv_s = 1.0;
     bool any = false, inclusive = false, found = false;
     uint32_t tri = 0, inst = 0, cur = RT_WALK_DONE;
@@ -508,6 +549,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                     double tn;
                     if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn)) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
+                        if (LDS) { s32 = slab32_setup(lr.o, inv, mesh.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
                         lnodes = reinterpret_cast<const LBvhNode*>(rt_lds_base() + mesh.lds_node_off);
                         ltris = reinterpret_cast<const LMeshTri*>(rt_lds_base() + mesh.lds_tri_off);
@@ -518,24 +560,26 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
             }
         }
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
-            double tn0, tn1;
-            bool h0, h1;
+            bool h0, h1, swap;
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
+                float tn0, tn1;
                 const LBvhNode n = lds_node(lnodes + cur);
-                h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
-                h1 = slab_f32(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
+                h0 = slab32_box(n.lo[0], n.hi[0], s32, best32, tn0);
+                h1 = slab32_box(n.lo[1], n.hi[1], s32, best32, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             } else {
+                double tn0, tn1;
                 const DBvhNode& n = gnodes[cur];
                 h0 = slab(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
                 h1 = slab(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             }
             if (h0 && h1) {
-                bool swap = tn1 < tn0;
                 cur = swap ? c1 : c0;
                 push(swap ? c0 : c1);
             } else if (h0) cur = c0;
@@ -555,6 +599,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                             if (inclusive ? t <= tmax : t < tmax) found = true;
                         } else if (t < best) {
                             best = t; tri = base + i; found = true;
+                            if (LDS) best32 = slab32_limit(best);
                         }
                     }
                 }

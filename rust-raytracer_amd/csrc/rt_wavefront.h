@@ -357,6 +357,8 @@ k_wf_walk(DScene sc, WfArgs a) {
     uint32_t qinst = 0, qfound = 0, qca = 0;
     LRay lr; lr.o = mk3(0.0, 0.0, 0.0); lr.d = lr.o;
     d3 inv = lr.o;
+    Slab32 s32 = slab32_setup(lr.o, lr.o, 0.0);                      // (LDS walk: the f32 box test)
+    float best32 = 0.0f;
     double best = 0.0, tmax = 0.0, inv_s = 1.0;
     bool any = false, inclusive = false, found = false;
     uint32_t tri = 0, inst = 0, cur = RT_WALK_DONE;
@@ -450,6 +452,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                     double tn;
                     if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn)) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
+                        if (LDS) { s32 = slab32_setup(lr.o, inv, mesh.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
                         lnodes = reinterpret_cast<const LBvhNode*>(blob + mesh.lds_node_off);
                         ltris = reinterpret_cast<const LMeshTri*>(blob + mesh.lds_tri_off);
@@ -463,24 +466,26 @@ k_wf_walk(DScene sc, WfArgs a) {
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
             // (lanes still here: those descending) most of the wave waits at its leaves -> test those first
             if ((uint32_t)__popcll(__ballot(true)) * 8u < nwalk * a.descend_frac) break;
-            double tn0, tn1;
-            bool h0, h1;
+            bool h0, h1, swap;
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
+                float tn0, tn1;
                 const LBvhNode n = lds_node(lnodes + cur);
-                h0 = slab_f32(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
-                h1 = slab_f32(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
+                h0 = slab32_box(n.lo[0], n.hi[0], s32, best32, tn0);
+                h1 = slab32_box(n.lo[1], n.hi[1], s32, best32, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             } else {
+                double tn0, tn1;
                 const DBvhNode& n = gnodes[cur];
                 h0 = slab(n.lo[0], n.hi[0], lr.o, inv, best, tn0);
                 h1 = slab(n.lo[1], n.hi[1], lr.o, inv, best, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
+                swap = tn1 < tn0;
             }
             if (h0 && h1) {
-                bool swap = tn1 < tn0;
                 cur = swap ? c1 : c0;
                 push(swap ? c0 : c1);
             } else if (h0) cur = c0;
@@ -500,6 +505,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                             if (inclusive ? t <= tmax : t < tmax) found = true;
                         } else if (t < best) {
                             best = t; tri = base + i; found = true;
+                            if (LDS) best32 = slab32_limit(best);
                         }
                     }
                 }
