@@ -348,14 +348,17 @@ RT_DEV LMeshTri lds_tri(const LMeshTri* p) {
     u.w[0] = w[0]; u.w[1] = w[1]; u.w[2] = w[2]; u.w[3] = w[3];
     return u.t;
 }
-// Mesh::check_triangle (mesh.rs:416-443) on either triangle record
+// Mesh::check_triangle (mesh.rs:416-443) on either triangle record.  `limit`: a hit at or beyond it
+// (closest-hit query: the best distance so far; any-hit query: the distance of the light, itself
+// included when `inclusive`) changes nothing for the caller, so the three edge tests are skipped
+// for it; the result is what the full test followed by the caller's comparison gives.
 template <class TRI>
-RT_DEV bool mesh_tri_test(const TRI& tr, const LRay& r, double& t) {
+RT_DEV bool mesh_tri_test(const TRI& tr, const LRay& r, double limit, bool inclusive, double& t) {
     d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3), normal = ld3(tr.n);
     double origin_dot = dot(normal, r.o - v1);
     double direction_dot = dot(normal, r.d);
     double hit_distance = -origin_dot / direction_dot;
-    if (hit_distance > RT_MIN_DISTANCE) {
+    if (hit_distance > RT_MIN_DISTANCE && (inclusive ? hit_distance <= limit : hit_distance < limit)) {
         d3 p = r.o + (hit_distance * r.d);
         if (dot(cross(v2 - v1, p - v1), normal) < 0.0) return false;
         if (dot(cross(v3 - v2, p - v2), normal) < 0.0) return false;
@@ -428,7 +431,8 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
         for (uint32_t i = 0; i < cnt; ++i) {                     // the leaf's triangles
             double t;
             RT_COUNT(wk, tri_tests);
-            bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), r, t) : mesh_tri_test(gtris[base + i], r, t);
+            const double lim = any ? tmax : best; const bool incl = any && inclusive;
+            bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), r, lim, incl, t) : mesh_tri_test(gtris[base + i], r, lim, incl, t);
             if (hit) {
                 if (any) {
                     if (inclusive ? t <= tmax : t < tmax) { found = true; }
@@ -593,7 +597,8 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
                     RT_COUNT(wk, tri_tests);
-                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, t) : mesh_tri_test(gtris[base + i], lr, t);
+                    const double lim = any ? tmax : best; const bool incl = any && inclusive;
+                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, lim, incl, t) : mesh_tri_test(gtris[base + i], lr, lim, incl, t);
                     if (hit) {
                         if (any) {
                             if (inclusive ? t <= tmax : t < tmax) found = true;

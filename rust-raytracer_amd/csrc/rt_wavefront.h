@@ -23,7 +23,31 @@
 #include "rt_kernels.h"
 
 #define RT_WF_LDS_STACK 12     // BVH walk stack entries per thread kept in LDS by k_wf_walk
-#define RT_WF_WALK_FIXED_BYTES(threads) ((threads) * RT_WF_LDS_STACK * 4u + 2048u)   // k_wf_walk's LDS apart from the BVH blob: walk stacks, list starts
+// What the walk needs to know of a mesh instance (DInstance -> DPrim -> DMesh), gathered into one record:
+// the first RT_WF_WALK_TABLE of them are built once per workgroup and kept in LDS, so that a lane
+// that takes a new query reads them with one hop instead of a chain of four dependent global loads.
+struct WalkInst {
+    double w2l[12];
+    double uniform_s, uniform_inv_s;
+    double lo[3], hi[3];
+    double max_abs;
+    uint32_t node_off, tri_off, lds_node_off, lds_tri_off, inst, is_root;
+};
+#define RT_WF_WALK_TABLE 8u
+#define RT_WF_WALK_FIXED_BYTES(threads) ((threads) * RT_WF_LDS_STACK * 4u + 2048u + RT_WF_WALK_TABLE * (uint32_t)sizeof(WalkInst))   // k_wf_walk's LDS apart from the BVH blob: walk stacks, list starts, instance table
+RT_DEV WalkInst walk_inst(const DScene& sc, uint32_t m) {
+    WalkInst w;
+    w.inst = sc.mesh_instances[m];
+    const DInstance& in = sc.instances[w.inst];
+    const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
+    for (int k = 0; k < 12; ++k) w.w2l[k] = in.x.w2l.r[k];
+    w.uniform_s = in.x.uniform_s; w.uniform_inv_s = in.x.uniform_inv_s;
+    for (int k = 0; k < 3; ++k) { w.lo[k] = mesh.lo[k]; w.hi[k] = mesh.hi[k]; }
+    w.max_abs = mesh.max_abs;
+    w.node_off = mesh.node_off; w.tri_off = mesh.tri_off; w.lds_node_off = mesh.lds_node_off; w.lds_tri_off = mesh.lds_tri_off;
+    w.is_root = in.is_root;
+    return w;
+}
 // Every queue is cut into RT_WF_Q sub-queues with a fill counter each.  Appending costs one
 // atomic per wave on the counter; on a single counter those serialise (~12 ns each, 4-6 million
 // per generation), spread over 256 counters they do not.  Workgroup b reads and appends to
@@ -314,7 +338,9 @@ k_wf_walk(DScene sc, WfArgs a) {
     uint32_t* lstack = reinterpret_cast<uint32_t*>(rt_lds_dynamic) + threadIdx.x;
     const uint32_t lstride = blockDim.x;
     uint32_t* starts = reinterpret_cast<uint32_t*>(rt_lds_dynamic) + (size_t)blockDim.x * RT_WF_LDS_STACK;   // RT_WF_Q + 1 words, padded to 2 KB
-    const uint8_t* blob = rt_lds_dynamic + (size_t)blockDim.x * RT_WF_LDS_STACK * 4u + 2048u;
+    WalkInst* wtable = reinterpret_cast<WalkInst*>(rt_lds_dynamic + (size_t)blockDim.x * RT_WF_LDS_STACK * 4u + 2048u);
+    const uint8_t* blob = rt_lds_dynamic + RT_WF_WALK_FIXED_BYTES(blockDim.x);
+    if (threadIdx.x >= 64 && threadIdx.x - 64 < min(sc.num_mesh_instances, RT_WF_WALK_TABLE)) wtable[threadIdx.x - 64] = walk_inst(sc, threadIdx.x - 64);
     if (threadIdx.x < 64) {                                          // exclusive scan of the list lengths by the first wave
         uint32_t run = 0;
         for (uint32_t base = 0; base < a.sq_count; base += 64) {
@@ -346,7 +372,7 @@ k_wf_walk(DScene sc, WfArgs a) {
     uint32_t* gstack = a.walk_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (RT_BVH_STACK - RT_WF_LDS_STACK);
     Work<COUNT> wk = {};
     // The chain's walk lists are read as one: `starts` holds where each begins in the joint numbering.
-    uint32_t chunk_next = 0, chunk_end = 0;                          // the wave's reserved part of the joint list
+    uint32_t chunk_next = 0, chunk_end = 0, chunk_list = 0;          // the wave's reserved part of the joint list, and the list its first entry lies in
     bool dry = total == 0;                                           // wave-uniform: the joint list is used up
     bool have = false, walking = false;
     uint32_t qe = 0;                                                 // the query's entry in its arrays
@@ -413,14 +439,19 @@ k_wf_walk(DScene sc, WfArgs a) {
                     base = __shfl(base, leader);
                     chunk_next = base; chunk_end = base + chunk;
                     if (base >= total) dry = true;
+                    else {                                            // which list does it start in?  (largest l with starts[l] <= base)
+                        uint32_t lo = 0, hi = a.sq_count;
+                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= base) lo = mid; else hi = mid; }
+                        chunk_list = lo;
+                    }
                 }
                 const uint32_t avail = dry ? 0u : min(chunk_end, total) - chunk_next;
                 const uint32_t idx = chunk_next + rank;
                 chunk_next += min(nwant, avail);
                 if (want && rank < avail) {
-                    // which list does joint entry idx belong to?  (largest l with starts[l] <= idx)
-                    uint32_t lo = 0, hi = a.sq_count;
-                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= idx) lo = mid; else hi = mid; }
+                    // the list joint entry idx belongs to: the chunk's, or one of the next few (starts[sq_count] = total > idx)
+                    uint32_t lo = chunk_list;
+                    while (starts[lo + 1] <= idx) ++lo;
                     const uint32_t e = a.walk_list[(size_t)(a.sq_base + lo) * (2u * a.sub) + (idx - starts[lo])];
                     qshadow = (e & 0x80000000u) != 0;
                     qe = e & 0x7FFFFFFFu;
@@ -439,23 +470,32 @@ k_wf_walk(DScene sc, WfArgs a) {
             if (need && have) {
                 RT_PROF(wk, PF_T_REFILLS, PF_T_REFILL_LANES);
                 do {   // next mesh instance whose bounding box the ray reaches
-                    inst = sc.mesh_instances[m];
-                    const DInstance& in = sc.instances[inst];
-                    const DMesh& mesh = sc.meshes[sc.prims[in.prim].ref];
+                    const WalkInst wi = m < RT_WF_WALK_TABLE ? wtable[m] : walk_inst(sc, m);
+                    inst = wi.inst;
                     double s;
-                    lr = to_local(in.x, qo, qd, s, inv_s);
+                    {   // to_local (rt_trace.h) on the record's copy of the instance transform
+                        lr.o = mk3(((wi.w2l[0] * qo.x + wi.w2l[1] * qo.y) + wi.w2l[2] * qo.z) + wi.w2l[3],
+                                   ((wi.w2l[4] * qo.x + wi.w2l[5] * qo.y) + wi.w2l[6] * qo.z) + wi.w2l[7],
+                                   ((wi.w2l[8] * qo.x + wi.w2l[9] * qo.y) + wi.w2l[10] * qo.z) + wi.w2l[11]);
+                        const d3 v = mk3((wi.w2l[0] * qd.x + wi.w2l[1] * qd.y) + wi.w2l[2] * qd.z,
+                                         (wi.w2l[4] * qd.x + wi.w2l[5] * qd.y) + wi.w2l[6] * qd.z,
+                                         (wi.w2l[8] * qd.x + wi.w2l[9] * qd.y) + wi.w2l[10] * qd.z);
+                        if (wi.uniform_inv_s != 0.0) { inv_s = wi.uniform_inv_s; s = wi.uniform_s; }
+                        else { s = length(v); inv_s = 1.0 / s; }
+                        lr.d = v * inv_s;
+                    }
                     RT_COUNT(wk, instance_tests);
                     inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
                     tmax = qt * s;
-                    inclusive = in.is_root != 0;
+                    inclusive = wi.is_root != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
-                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn)) {
+                    if (slab(wi.lo, wi.hi, lr.o, inv, tmax, tn)) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
-                        if (LDS) { s32 = slab32_setup(lr.o, inv, mesh.max_abs); best32 = slab32_limit(best); }
-                        gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
-                        lnodes = reinterpret_cast<const LBvhNode*>(blob + mesh.lds_node_off);
-                        ltris = reinterpret_cast<const LMeshTri*>(blob + mesh.lds_tri_off);
+                        if (LDS) { s32 = slab32_setup(lr.o, inv, wi.max_abs); best32 = slab32_limit(best); }
+                        gnodes = sc.bvh_nodes + wi.node_off; gtris = sc.mesh_tris + wi.tri_off;
+                        lnodes = reinterpret_cast<const LBvhNode*>(blob + wi.lds_node_off);
+                        ltris = reinterpret_cast<const LMeshTri*>(blob + wi.lds_tri_off);
                     } else if (++m == nm) {
                         finish_query();
                     }
@@ -499,7 +539,8 @@ k_wf_walk(DScene sc, WfArgs a) {
                 for (uint32_t i = 0; i < cnt; ++i) {
                     double t;
                     RT_COUNT(wk, tri_tests);
-                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, t) : mesh_tri_test(gtris[base + i], lr, t);
+                    const double lim = any ? tmax : best; const bool incl = any && inclusive;
+                    bool hit = LDS ? mesh_tri_test(lds_tri(ltris + base + i), lr, lim, incl, t) : mesh_tri_test(gtris[base + i], lr, lim, incl, t);
                     if (hit) {
                         if (any) {
                             if (inclusive ? t <= tmax : t < tmax) found = true;
