@@ -125,7 +125,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    scenes = importlib.import_module("rust-raytracer_amd.scenes")
+    scenes = importlib.import_module("harness.scenes")
     render = importlib.import_module("rust-raytracer_amd.render")
     rdist = importlib.import_module("rust-raytracer_amd.dist")
     abi = importlib.import_module("rust-raytracer_amd._abi")

@@ -1,15 +1,18 @@
-"""Named scenes: the reference's test scenes as transcribed in host/scenes.cpp.
+"""Named scenes: the reference's test scenes as transcribed in harness/scenes.cpp.
 
 `Scene(name)` builds the scene in the C++ host layer and exposes the pointer to its
 flat RtSceneDesc plus the image size / camera / config the reference test uses."""
 import ctypes as C
 import os
 
-from ._abi import RtCamera, RtImageDim, RtRenderConfig
+import importlib
+
+_abi = importlib.import_module("rust-raytracer_amd._abi")
+RtCamera, RtImageDim, RtRenderConfig = _abi.RtCamera, _abi.RtImageDim, _abi.RtRenderConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-HOST_LIB = os.path.join(_HERE, "host", "libraytracer_host.so")
+HOST_LIB = os.path.join(_HERE, "libraytracer_host.so")
 
 _lib = None
 

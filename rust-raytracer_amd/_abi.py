@@ -1,6 +1,6 @@
 """ctypes mirror of the POD structs in include/rt_amd.h that cross the C ABI by value
 or by pointer from Python.  RtSceneDesc itself is never built in Python: the host
-library (host/scenes.cpp) produces it and Python only carries the pointer."""
+harness (harness/scenes.cpp) produces it and Python only carries the pointer."""
 import ctypes as C
 
 RT_NONE = 0xFFFFFFFF

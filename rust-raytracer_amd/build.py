@@ -2,7 +2,7 @@
 
   csrc/librt_amd.so            HIP render path for gfx950 (hipcc cross-compiles without a GPU); the kernel
                                variants under csrc/variants/ are separate translation units built in parallel
-  host/libraytracer_host.so    C++ mirror of the reference API + the transcribed test scenes
+  ../harness/libraytracer_host.so   (test harness) C++ mirror of the reference API + the transcribed test scenes
 """
 import os
 import subprocess
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(HERE, "csrc", "librt_amd.so")
-HOST_LIB = os.path.join(HERE, "host", "libraytracer_host.so")
+HOST_LIB = os.path.join(ROOT, "harness", "libraytracer_host.so")
 
 # -ffp-contract=off keeps the device arithmetic un-fused like the reference's (Rust never
 # contracts a*b+c); RT_FP_CONTRACT=fast trades that for FMA throughput.
@@ -60,7 +60,7 @@ def build_hip(force=False, jobs=None):
 
 
 def build_host(force=False):
-    src_dir = os.path.join(HERE, "host")
+    src_dir = os.path.join(ROOT, "harness")
     sources = [os.path.join(src_dir, f) for f in ("raytracer.cpp", "scenes.cpp", "raytracer.hpp")]
     sources.append(os.path.join(INCLUDE, "rt_amd.h"))
     if force or _newer(HOST_LIB, sources):

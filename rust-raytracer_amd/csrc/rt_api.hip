@@ -557,7 +557,8 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         wa.out_rays = queue(w.wf_rays[0], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
         hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
         HIP_TRY(hipGetLastError());
-        const uint32_t chains = fixed_mem ? 1u : wf_chains((size_t)W * num_rows);
+        uint32_t chains = fixed_mem ? 1u : wf_chains((size_t)W * num_rows);
+        if (!fixed_mem) { const char* pe = std::getenv(mode == 0 ? "RT_WF_CHAINS_P0" : "RT_WF_CHAINS_P1"); if (pe) { long v = std::atol(pe); chains = v >= 4 ? 4u : (v >= 2 ? 2u : 1u); } }
         uint32_t* const overflow0 = wa.walk_overflow;
         if (chains > 1) {                                             // the other chains start once generation 0 is in the queues
             HIP_TRY(hipEventRecord(s->chain_fork, stream));

@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def scenes_mod():
-    return importlib.import_module("rust-raytracer_amd.scenes")
+    return importlib.import_module("harness.scenes")
 
 
 @pytest.fixture(scope="session")

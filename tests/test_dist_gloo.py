@@ -35,7 +35,7 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    scenes = importlib.import_module("rust-raytracer_amd.scenes")
+    scenes = importlib.import_module("harness.scenes")
     rdist = importlib.import_module("rust-raytracer_amd.dist")
     s = scenes.Scene("glass_monkey")
     dim, cam, cfg = s.view(width=WIDTH, height=HEIGHT, anti_alias=True, seed=1)

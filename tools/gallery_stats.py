@@ -5,7 +5,7 @@ import numpy as np
 from PIL import Image
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-scenes = importlib.import_module("rust-raytracer_amd.scenes")
+scenes = importlib.import_module("harness.scenes")
 render = importlib.import_module("rust-raytracer_amd.render")
 
 def blocks(img, b=16):

@@ -4,7 +4,7 @@ Usage: python tools/gpu_parity.py [--size N] [--aa 0|1] scene [scene ...]"""
 import argparse, importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-scn = importlib.import_module("rust-raytracer_amd.scenes")
+scn = importlib.import_module("harness.scenes")
 rnd = importlib.import_module("rust-raytracer_amd.render")
 from oracle import binding as orc
 

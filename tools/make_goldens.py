@@ -2,13 +2,13 @@
 """Generates tests/golden/oracle_<scene>.npz: outputs of the CPU oracle (pinned against
 the reference's gallery image, see tests/test_oracle_golden.py) for the scenes of the five
 benchmark configurations and one scene per primitive / shader family, at 64 pixels wide,
-anti-aliasing on, seed 1.  Inputs are the named scenes of rust-raytracer_amd/host/scenes.cpp;
+anti-aliasing on, seed 1.  Inputs are the named scenes of harness/scenes.cpp;
 expected outputs are RGB8, primary hit ids and the AA mask."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-scn = importlib.import_module("rust-raytracer_amd.scenes")
+scn = importlib.import_module("harness.scenes")
 from oracle import binding as orc
 
 SCENES = ["basic_setup_scene", "plane_test_1", "cube_test_1", "shadow_test_1", "child_transform_test_1",

@@ -3,7 +3,7 @@
 Usage: prof_rank.py scene width height rank nranks [frames]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-scn = importlib.import_module("rust-raytracer_amd.scenes")
+scn = importlib.import_module("harness.scenes")
 rnd = importlib.import_module("rust-raytracer_amd.render")
 name, w, h, rank, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 frames = int(sys.argv[6]) if len(sys.argv) > 6 else 2
