@@ -112,7 +112,7 @@ struct Color {
     }
     // the constants the reference's scenes use (src/color/consts.rs)
     static const Color MAROON, FIREBRICK, RED, YELLOW, GREEN, LIME, CYAN, NAVY, BLUE, PURPLE, MAGENTA,
-        CHOCOLATE, ROSY_BROWN, MISTY_ROSE, BLACK, ALMOST_BLACK, LIGHT_BLACK, GRAY, WHITE, ORANGE, TEAL;
+        CHOCOLATE, ROSY_BROWN, MISTY_ROSE, BLACK, ALMOST_BLACK, LIGHT_BLACK, GRAY, WHITE, ORANGE, TEAL, GOLD, BROWN, LAVENDER;
 };
 inline constexpr Color Color::MAROON{0.5, 0, 0}, Color::FIREBRICK{0.695312, 0.132812, 0.132812},
     Color::RED{0.996094, 0, 0}, Color::YELLOW{0.996094, 0.996094, 0}, Color::GREEN{0, 0.5, 0},
@@ -121,7 +121,8 @@ inline constexpr Color Color::MAROON{0.5, 0, 0}, Color::FIREBRICK{0.695312, 0.13
     Color::CHOCOLATE{0.820312, 0.410156, 0.117188}, Color::ROSY_BROWN{0.734375, 0.558594, 0.558594},
     Color::MISTY_ROSE{0.996094, 0.890625, 0.878906}, Color::BLACK{0, 0, 0},
     Color::ALMOST_BLACK{0.004, 0.004, 0.004}, Color::LIGHT_BLACK{0.1, 0.1, 0.1}, Color::GRAY{0.5, 0.5, 0.5},
-    Color::WHITE{1, 1, 1}, Color::ORANGE{0.996094, 0.644531, 0}, Color::TEAL{0, 0.5, 0.5};
+    Color::WHITE{1, 1, 1}, Color::ORANGE{0.996094, 0.644531, 0}, Color::TEAL{0, 0.5, 0.5},
+    Color::GOLD{0.996094, 0.839844, 0}, Color::BROWN{0.644531, 0.164062, 0.164062}, Color::LAVENDER{0.898438, 0.898438, 0.976562};
 
 // ---------------------------------------------------------------- description builder
 // Accumulates the flat arrays of an RtSceneDesc.  Shared sub-objects (the same

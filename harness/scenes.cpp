@@ -503,7 +503,7 @@ View bump_map_basic_1() {                                                // bump
         }));
     return {scene, image(500, 500), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
 }
-View octahedron_basic() {                                                // polyhedra_test.rs:70-101 (d8_num.png → test3.png)
+View octahedron_basic_n(int n) {                                         // polyhedra_test.rs:70-101: two cameras
     using namespace mesh_test;
     Scene scene = build_scene(
         {light1(), light2(), light3()}, no_ambient(), nullptr,
@@ -512,10 +512,11 @@ View octahedron_basic() {                                                // poly
                 default_material(Color::WHITE), default_material(Color::WHITE), default_material(Color::RED),
                 default_material(Color::CYAN), default_material(Color::GREEN), ReflectionShader::new_(Color::WHITE)}),
             geometry_node(translation(0.0, 0.0, 0.0),
-                          texture_phong_material("assets/images/textures/test3.png", 1.0, 0.0, 0.0, 2.0),
+                          texture_phong_material("assets/images/textures/d8_num.png", 1.0, 0.0, 0.0, 2.0),
                           Polyhedron::octahedron(200.0), {}),
         }));
-    return {scene, image(512, 512), camera(dvec3(-300.0, 0.0, 300.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+    return {scene, image(512, 512), n == 1 ? camera(dvec3(-300.0, 0.0, 300.0), dvec3(0.0, 0.0, 0.0)) : camera(dvec3(300.0, 0.0, -300.0), dvec3(0.0, 0.0, 0.0)),
+            RenderConfig::default_()};
 }
 View polyhedron_basic() {                                                // polyhedra_test.rs:26-68 (granite.jpg → marble.png)
     using namespace mesh_test;
@@ -537,6 +538,256 @@ View polyhedron_basic() {                                                // poly
         }));
     return {scene, image(512, 512), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
 }
+
+// =========================================================== tests/basic_test.rs (the two Phong tests)
+View phong_test_n(int n) {                                               // :36-58 (root replaced by a primitive-less node: renders black)
+    Scene test_scene = setup_scene();
+    test_scene.add_light(PointLight::new_(dvec3(200.0, 200.0, 200.0), Color::new_(1.0, 1.0, 1.0), 1.0, {1.0, 0.0, 0.0}));
+    auto root = SceneNode::new_();
+    root->set_material(PhongShader::new_(Color::WHITE * 0.1, Color::WHITE * 0.9, Color::WHITE * 0.1, n == 1 ? 2.0 : 4.0));
+    test_scene.root = root;
+    return {test_scene, square_image(512), setup_camera(), RenderConfig::default_()};
+}
+
+// =========================================================== tests/scene_test.rs (the rest)
+namespace scene_test {
+View scene_light_1(int i) {                                              // :101-115, i = 1..10
+    Scene s = Scene::new_();
+    s.root = create_interior_box(room_size);
+    const double a = room_size / 3.0, h = (room_size / 2.0) * 0.6;
+    for (DVec3 p : {dvec3(a, h, a), dvec3(-a, h, a), dvec3(a, h, -a), dvec3(-a, h, -a)})
+        s.add_light(PointLight::new_(p, Color::new_(1, 1, 1), 2000.0 * i, {0.0, 0.0, 4.0 * PI}));
+    return {s, image(512, 512), camera(dvec3(0.0, 0.0, 200.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+}
+View translucent_shadow() {                                              // :155-171, i = 9 (forest2.jpg is a missing blob → sky_ocean.jpg)
+    Scene scene = Scene::new_();
+    scene.root->add_child(create_translucent_cube(160.0, translation(0.0, 100.0, 0.0) * scaling(1.0, 1.0, 1.0 / 160.0 * 9.0),
+                                                  Color::WHITE - Color::LIGHT_BLACK, 1.52));
+    scene.root->add_child(create_floor(600.0, Color::WHITE));
+    scene.add_light(PointLight::new_(dvec3(-100.0, 300.0, -300.0), Color::new_(1, 1, 1), 150000.0, {0.0, 0.0, 1.0 * PI}));
+    scene.set_background_from_path("assets/images/backgrounds/sky_ocean.jpg");
+    return {scene, image(1920, 1080), camera(dvec3(0.0, 200.0, 400.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+}
+}  // namespace scene_test
+
+// =========================================================== tests/bump_map_test.rs:55-79
+View bump_map_basic_2() {
+    auto dot = [] { return scene_test::test_bump_shader(Color::WHITE, BumpMap::from_path("assets/images/bump_maps/dot.png", 1.0)); };
+    Scene scene = build_scene(
+        {PointLight::new_(dvec3(100.0, 200.0, -200.0), Color::new_(1, 1, 1), 300000.0, {0.0, 0.0, 1.0 * PI})}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                dot(), dot(), dot(), dot(), dot(),
+                scene_test::test_bump_shader(Color::WHITE, BumpMap::from_path("assets/images/bump_maps/bumps.png", 1.0))}),
+        }));
+    return {scene, image(500, 500), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+
+// =========================================================== tests/transparency_test.rs
+namespace transparency_test {
+LightableBox light1() { return PointLight::new_(dvec3(0.0, 300.0, 0.0), Color::new_(1, 1, 1), 150000.0, {0.0, 0.0, 1.0 * PI}); }
+LightableBox light2() { return PointLight::new_(dvec3(-300.0, 300.0, 300.0), Color::new_(1, 1, 1), 150000.0, {0.0, 0.0, 1.0 * PI}); }
+LightableBox light3() { return PointLight::new_(dvec3(-300.0, -340.0, 300.0), Color::new_(1, 1, 1), 150000.0, {0.0, 0.0, 1.0 * PI}); }
+View transparent_shapes() {                                              // :26-60
+    using mesh_test::default_material;
+    Scene scene = build_scene(
+        {light1(), light2(), light3()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                default_material(Color::GOLD), default_material(Color::BROWN), default_material(Color::FIREBRICK),
+                default_material(Color::CYAN), default_material(Color::ORANGE), default_material(Color::LAVENDER)}),
+            geometry_node(translation(-150.0, 0.0, 0.0), TranslucentShader::new_(Color::WHITE, 1.52), Sphere::from_radius(160.0), {}),
+            geometry_node(translation(150.0, -220.0, 80.0), TranslucentShader::new_(Color::WHITE, 2.42), Cube::new_(160.0), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+View transparent_orb() {                                                 // :62-85
+    SkyBox sky = SkyBox::from_path("assets/images/backgrounds/sky_ocean.jpg", rotation(Axis::Y, 20.0));
+    Scene scene = build_scene(
+        {light1(), light2(), light3()}, no_ambient(), &sky,
+        scene_node(DMat4::identity(), {
+            geometry_node(translation(0.0, 0.0, 0.0), TranslucentShader::new_(Color::WHITE, 1.52), Sphere::from_radius(160.0), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(0.0, 0.0, 300.0), dvec3(0.0, 0.0, -0.0)), RenderConfig::default_()};
+}
+}  // namespace transparency_test
+
+// =========================================================== tests/normal_map_test.rs
+// brick_shader (src/util.rs:13-29); normal_maps/brick_wall.jpg is a missing blob → brick_wall_01.png
+ShadableBox brick_shader() {
+    auto brick = ChainShader::new_();
+    brick->push_shader(NormalMapShader::new_(NormalMap::from_path("assets/images/normal_maps/brick_wall_01.png")));
+    brick->push_shader(PhongShader::new_(Color::WHITE * 0.9, Color::WHITE * 0.1, Color::WHITE * 0.0, 2.0));
+    return brick;
+}
+View normal_map_room_n(int n) {                                          // :26-76
+    using mesh_test::default_material;
+    LightableBox light = n == 1 ? PointLight::new_(dvec3(200.0, 200.0, -200.0), Color::new_(1, 1, 1), 300000.0, {0.0, 0.0, 1.0 * PI})
+                                : PointLight::new_(dvec3(200.0, 200.0, 200.0), Color::new_(1, 1, 1), 300000.0, {0.0, 0.0, 1.0 * PI});
+    ShadableBox brick = brick_shader();
+    Scene scene = build_scene(
+        {light}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                default_material(Color::WHITE), default_material(Color::WHITE), brick,
+                default_material(Color::CYAN), default_material(Color::WHITE), brick}),
+        }));
+    return {scene, image(1920, 1080), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+
+// =========================================================== tests/texture_test.rs
+// Large or missing textures are replaced by images that are already committed: granite.jpg (12 MB raw)
+// → marble.png, wood_boards.jpg (35 MB) → light_wood.jpg, brick_wall.jpg (missing blob) → smooth_concrete.jpg,
+// orange_leather.jpg (12 MB) → smooth_concrete.jpg.
+namespace texture_test {
+using namespace mesh_test;
+View texture_room() {                                                    // :34-69
+    Scene scene = build_scene(
+        {light1(), light2(), light3()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                texture_phong_material("assets/images/textures/marble.png", 1.0, 0.0, 0.0, 2.0),
+                texture_phong_material("assets/images/textures/light_wood.jpg", 1.0, 0.0, 0.0, 1.0),
+                texture_phong_material("assets/images/textures/smooth_concrete.jpg", 1.0, 0.0, 0.0, 1.0),
+                default_material(Color::CYAN),
+                texture_phong_material("assets/images/textures/smooth_concrete.jpg", 1.0, 0.0, 0.0, 1.0),
+                ReflectionShader::new_(Color::WHITE)}),
+            geometry_node(translation(-150.0, -270.0, 0.0),
+                          texture_phong_material("assets/images/textures/smooth_concrete.jpg", 1.0, 0.0, 0.0, 1.0), Sphere::from_radius(80.0), {}),
+            geometry_node(translation(150.0, -270.0, 80.0),
+                          texture_phong_material("assets/images/textures/cube_rgb_gradient.png", 0.5, 0.5, 0.0, 4.0), Cube::new_(160.0), {}),
+        }));
+    return {scene, image(5000, 5000), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+View texture_cube() {                                                    // :71-98
+    Scene scene = build_scene(
+        {light1(), light2(), light3(), light4()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                default_material(Color::WHITE), ReflectionShader::new_(Color::WHITE), ReflectionShader::new_(Color::WHITE),
+                default_material(Color::CYAN), default_material(Color::YELLOW), ReflectionShader::new_(Color::WHITE)}),
+            geometry_node(translation(0.0, 0.0, 0.0),
+                          texture_phong_material("assets/images/textures/cube_rgb_numbers.png", 0.5, 0.5, 0.0, 4.0), Cube::new_(160.0), {}),
+        }));
+    return {scene, image(1920, 1080), camera(dvec3(-310.0, 300.0, 300.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+}
+View skybox_test() {                                                     // :100-114: nothing but the sky box
+    SkyBox sky = SkyBox::from_path("assets/images/living_room.jpg", DMat4::identity());
+    Scene scene = build_scene({}, no_ambient(), &sky, scene_node(DMat4::identity(), {}));
+    return {scene, image(512, 512), camera(dvec3(-310.0, 300.0, 300.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+}
+View correlated_texture() {                                              // :116-138
+    auto tiny = [](double d, double s, double sh) { return texture_phong_material("assets/images/tiny.png", d, s, 0.0, sh); };
+    Scene scene = build_scene(
+        {light1(), light2(), light3()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                tiny(4.0, 6.0, 2.0), tiny(1.0, 0.0, 1.0), tiny(1.0, 0.0, 1.0), default_material(Color::CYAN), tiny(1.0, 0.0, 1.0), tiny(1.0, 0.0, 1.0)}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+View plane_texture() {                                                   // :140-160
+    Scene scene = build_scene(
+        {PointLight::new_(dvec3(0.0, 0.0, 1000.0), Color::new_(1, 1, 1), 1.0, {1.0, 0.0, 0.0})}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            geometry_node(translation(0.0, 0.0, 0.0), texture_phong_material("assets/images/textures/keanu.jpg", 1.0, 0.0, 0.0, 4.0),
+                          Plane::with_tangent(dvec3(0.0, 0.0, 0.0), dvec3(0.0, 0.0, 1.0), dvec3(0.0, 1.0, 0.0)), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(0.0, 0.0, 1.0), dvec3(1.0, 0.0, 1.0)), RenderConfig::default_()};
+}
+}  // namespace texture_test
+
+// =========================================================== tests/dice_scene.rs
+// nice_room.jpg (23 MB raw) → sky_ocean.jpg, gurf-1.jpg (11 MB) → keanu.jpg, granite.jpg → marble.png
+namespace dice_scene {
+LightableBox light1() { return PointLight::new_(dvec3(0.0, 100.0, 0.0), Color::new_(1, 1, 1), 90000.0, {0.0, 0.0, 4.0 * PI}); }
+LightableBox light2() { return PointLight::new_(dvec3(-50.0, 100.0, 100.0), Color::new_(1, 1, 1), 75000.0, {0.0, 0.0, 4.0 * PI}); }
+LightableBox light3() { return PointLight::new_(dvec3(50.0, 100.0, -100.0), Color::new_(1, 1, 1), 75000.0, {0.0, 0.0, 4.0 * PI}); }
+LightableBox front_light() { return PointLight::new_(dvec3(0.0, 0.0, 100.0), Color::new_(1, 1, 1), 1.0, {1.0, 0.0, 0.0}); }
+ShadableBox wood_material() {                                            // :26-39
+    return CompositeShader::from_shaders({
+        {0.8, MixShader::from_shaders({
+                  PhongShader::new_(Color::WHITE * 0.5, Color::WHITE * 0.5, Color::BLACK, 2.0),
+                  TextureShader::new_(ImageTexture::from_path("assets/images/textures/light_wood.jpg")),
+              })},
+        {0.2, ReflectionShader::new_(Color::WHITE)},
+    });
+}
+SceneNodeBox make_character_sheet(double size, DMat4 transform) {       // :41-48
+    return geometry_node(transform * translation(0.0, 0.01, 0.0) * rotation(Axis::X, -90.0),
+                         texture_phong_material("assets/images/textures/keanu.jpg", 1.0, 0.0, 0.0, 1.0), Rectangle::new_(1.7 * size, 2.2 * size), {});
+}
+SceneNodeBox make_d6(double size, DMat4 transform) {                     // :50-63
+    return geometry_node(transform * translation(0.0, size / 2.0, 0.0),
+                         ChainShader::from_shaders({
+                             NormalMapShader::new_(BumpMap::from_path("assets/images/bump_maps/d6_num.png", 10.0)),
+                             CompositeShader::from_shaders({
+                                 {0.05, ReflectionShader::new_(Color::WHITE)},
+                                 {0.95, texture_phong_material("assets/images/textures/d6_num.png", 0.9, 0.1, 0.0, 2.0)},
+                             }),
+                         }),
+                         Cube::new_(size), {});
+}
+SceneNodeBox make_d4(double size, DMat4 transform) {                     // :65-72
+    return geometry_node(transform, texture_phong_material("assets/images/textures/d4_num.png", 1.0, 0.0, 0.0, 1.0), Tetrahedron::new_(size), {});
+}
+View dice_scene_view(bool hi_res) {                                      // :74-107
+    SkyBox sky = SkyBox::from_path("assets/images/backgrounds/sky_ocean.jpg", rotation(Axis::Y, 20.0));
+    Scene scene = build_scene(
+        {light1(), light2()}, no_ambient(), &sky,
+        scene_node(DMat4::identity(), {
+            create_floor_from_material(200.0, wood_material()),
+            make_character_sheet(30.0, translation(-20.0, 0.0, 50.0) * rotation(Axis::Y, 230.0)),
+            make_d6(5.0, translation(-30.0, 0.0, 50.0)),
+            make_d4(5.0, translation(-20.0, 0.0, 50.0)),
+        }));
+    RenderConfig config = RenderConfig::default_();
+    if (hi_res) config.anti_alias = false;
+    return {scene, hi_res ? image(1920, 1080) : image(192, 108), camera(dvec3(-30.0, 20.0, 70.0), dvec3(50.0, -50.0, -80.0)), config};
+}
+View polygon_basic() {                                                   // :109-133
+    Scene scene = build_scene(
+        {front_light()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            geometry_node(rotation(Axis::Y, 0.0), texture_phong_material("assets/images/textures/marble.png", 1.0, 0.0, 0.0, 1.0),
+                          Polygon::from_vertices({dvec3(-10.0, -10.0, 0.0), dvec3(0.0, -10.0, 0.0), dvec3(10.0, 0.0, 0.0), dvec3(10.0, 10.0, 0.0)}), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(0.0, 0.0, 10.0), dvec3(0.0, 0.0, -10.0)), RenderConfig::default_()};
+}
+View triangle_basic() {                                                  // :135-155
+    Scene scene = build_scene(
+        {front_light()}, no_ambient(), nullptr,
+        scene_node(DMat4::identity(), {
+            geometry_node(rotation(Axis::Y, 0.0), texture_phong_material("assets/images/textures/marble.png", 1.0, 0.0, 0.0, 1.0),
+                          Triangle::from_vertices(dvec3(-10.0, -10.0, 0.0), dvec3(0.0, -10.0, 0.0), dvec3(10.0, 10.0, 0.0)), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(0.0, 0.0, 10.0), dvec3(0.0, 0.0, -10.0)), RenderConfig::default_()};
+}
+View tetrahedron_basic() {                                               // :157-173
+    Scene scene = build_scene(
+        {light1(), light2(), light3()}, no_ambient(), nullptr,
+        scene_node(rotation(Axis::X, -50.0), {make_d4(30.0, translation(0.0, 0.0, 0.0))}));
+    return {scene, image(512, 512), camera(dvec3(0.0, 20.0, 40.0), dvec3(0.0, 0.0, 0.0)), RenderConfig::default_()};
+}
+}  // namespace dice_scene
+
+// =========================================================== DirectionLight (src/light.rs:82-120): no reference test uses it
+// The room of polyhedron_basic lit by one directional light (plus a weak point light, so that both light
+// paths meet in one Phong evaluation), a sphere and a cube to cast shadows, a mirror wall.
+View direction_light_room() {
+    using namespace mesh_test;
+    Scene scene = build_scene(
+        {DirectionLight::new_(dvec3(0.3, 1.0, 0.5), Color::new_(1.0, 0.9, 0.8), 0.8), light2()}, AmbientLight::new_(Color::WHITE, 0.1), nullptr,
+        scene_node(DMat4::identity(), {
+            create_room_from_material(700.0, RoomMaterialScheme{
+                default_material(Color::WHITE), default_material(Color::WHITE), default_material(Color::RED),
+                default_material(Color::CYAN), default_material(Color::GREEN), ReflectionShader::new_(Color::WHITE)}),
+            geometry_node(translation(-120.0, -250.0, 0.0), default_material(Color::YELLOW), Sphere::from_radius(100.0), {}),
+            geometry_node(translation(150.0, -270.0, 80.0) * rotation(Axis::Y, 30.0), default_material(Color::WHITE), Cube::new_(160.0), {}),
+        }));
+    return {scene, image(512, 512), camera(dvec3(-300.0, 0.0, 300.0), dvec3(350.0, -350.0, -350.0)), RenderConfig::default_()};
+}
+
 // A room holding the primitives no reference test instantiates directly as a node
 // (Triangle, Polygon, Tetrahedron, Inverted, Plane) so that every Intersectable is covered.
 View primitive_zoo() {
@@ -596,7 +847,29 @@ const std::vector<Entry>& registry() {
         {"xor_test", composite_shape_test::xor_test},
         {"reuleaux", composite_shape_test::reuleaux},
         {"bump_map_basic_1", bump_map_basic_1},
-        {"octahedron_basic", octahedron_basic},
+        {"octahedron_basic", [] { return octahedron_basic_n(1); }},
+        {"octahedron_basic_02", [] { return octahedron_basic_n(2); }},
+        {"phong_test_1", [] { return phong_test_n(1); }},
+        {"phong_test_2", [] { return phong_test_n(2); }},
+        {"anti_alias_comparison", [] { return scene_test::scene_test_n(5); }},   // anti_alias_test.rs:10-27: scene_test_5's scene and camera
+        {"scene_light_1_05", [] { return scene_test::scene_light_1(5); }},
+        {"translucent_shadow", scene_test::translucent_shadow},
+        {"bump_map_basic_2", bump_map_basic_2},
+        {"transparent_shapes", transparency_test::transparent_shapes},
+        {"transparent_orb", transparency_test::transparent_orb},
+        {"normal_map_room_1", [] { return normal_map_room_n(1); }},
+        {"normal_map_room_2", [] { return normal_map_room_n(2); }},
+        {"texture_room", texture_test::texture_room},
+        {"texture_cube", texture_test::texture_cube},
+        {"skybox_test", texture_test::skybox_test},
+        {"correlated_texture", texture_test::correlated_texture},
+        {"plane_texture", texture_test::plane_texture},
+        {"dice_scene_lo_res", [] { return dice_scene::dice_scene_view(false); }},
+        {"dice_scene_hi_res", [] { return dice_scene::dice_scene_view(true); }},
+        {"polygon_basic", dice_scene::polygon_basic},
+        {"triangle_basic", dice_scene::triangle_basic},
+        {"tetrahedron_basic", dice_scene::tetrahedron_basic},
+        {"direction_light_room", direction_light_room},
         {"polyhedron_basic", polyhedron_basic},
         {"primitive_zoo", primitive_zoo},
     };

@@ -79,6 +79,20 @@ struct Work {            // per-thread work counters, compiled out when COUNT is
 
 #define RT_COUNT(w, field) do { if (COUNT) (w).field++; } while (0)
 
+// Does a hit at world distance `t` on instance `i` replace the best one so far (`best` on `best_i`)?
+// The reference compares with strict '<' level by level, own primitive first, then the children in
+// insertion order (src/scene.rs:200-217): of hits at equal distance the earlier node in DFS
+// pre-order wins.  It measures those distances after a chain of per-level transforms, the flat
+// instance loop after one composed transform, so surfaces that tie exactly there can differ by a
+// few units in the last place here (and the other way round): distances within 8 ulp count as
+// equal and go to the earlier instance.
+RT_DEV bool replaces_hit(double t, uint32_t i, double best, uint32_t best_i, bool found) {
+    if (!found) return t < best;
+    const double tol = 8.0 * 2.220446049250313e-16 * fmax(fabs(t), fabs(best));
+    if (fabs(t - best) <= tol) return i < best_i;
+    return t < best;
+}
+
 // world/parent ray → local ray; returns s = |M_lin d| (local length of a unit parent step)
 RT_DEV LRay to_local(const DXform& x, d3 o, d3 d, double& s, double& inv_s) {
     LRay r;
@@ -616,7 +630,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                     if (any) { qfound = 1u; settled = true; }
                     else {
                         double tw = best * inv_s;
-                        if (tw < qt || (tw == qt && qfound && inst < qinst)) {
+                        if (replaces_hit(tw, inst, qt, qinst, qfound != 0u)) {
                             qt = tw; qinst = inst; qfound = 1u;
                             qct = best; qca = tri;
                         }
@@ -908,7 +922,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         }
         if (!got) return false;
         double tw = c.t * inv_s;
-        if (tw < best || (tw == best && found && i < hit.inst)) { best = tw; hit.inst = i; hit.c = c; found = true; }
+        if (replaces_hit(tw, i, best, hit.inst, found)) { best = tw; hit.inst = i; hit.c = c; found = true; }
         return false;
     };
     bool walked = false;

@@ -558,7 +558,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                     if (any) { qfound = 1u; settled = true; qchanged = true; }
                     else {
                         double tw = best * inv_s;
-                        if (tw < qt || (tw == qt && qfound && inst < qinst)) {
+                        if (replaces_hit(tw, inst, qt, qinst, qfound != 0u)) {
                             qt = tw; qinst = inst; qfound = 1u; qchanged = true;
                             qct = best; qca = tri;
                         }

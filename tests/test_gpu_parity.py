@@ -20,8 +20,20 @@ PSNR_DB = 50.0
 # so a handful of primary hit ids (and with them AA flags) may differ.
 # (The reference's +1.0 pixel offset puts row H/2-1 and column W/2-1 exactly on the optical
 # axis, so a camera aimed at a symmetric object shoots a whole row of rays along its edges.)
-TIE_SCENES = {"child_transform_test_1": 40, "subdivision_light": 4, "refraction_03": 8, "octahedron_basic": 6,
-              "subtraction_outside3": 6}
+TIE_SCENES = {"child_transform_test_1": 6, "subdivision_light": 2, "refraction_03": 12, "octahedron_basic": 4, "octahedron_basic_02": 5,
+              "triangle_basic": 2,
+              # camera on the room's axis, outside it, looking through a wall: the centre row and column of the image run along
+              # the seams where two (oversized, overlapping) walls meet at exactly equal distance - about half of those 2 x 112
+              # pixels go to the other wall, and with them its colour
+              "scene_light_1_05": 130}
+# Scenes whose colour is ill-conditioned on a few pixels, so that the last-place differences between the flattened and the
+# per-level transforms show: (fraction of pixels within 1 LSB, PSNR)
+#   plane_texture     an infinite textured plane seen at grazing angles: thousands of units away the texel is decided by
+#                     the last bits of the hit point
+#   triangle_basic    Triangle's surface coordinate takes sqrt(side_a^2 - x^2), which is NaN along the v1-v2 edge whenever
+#                     rounding makes it negative (plane.rs:129-136): one pixel at this size, in either renderer
+#   scene_light_1_05  the seam pixels above
+LOOSE_SCENES = {"plane_texture": (0.995, 50.0), "triangle_basic": (0.999, 40.0), "scene_light_1_05": (0.985, 34.0)}
 
 
 def small_view(scene, width, **kw):
@@ -52,10 +64,11 @@ def psnr(a, b):
 
 
 def check(got, want, name, hit_slack=0):
+    lsb_fraction, psnr_db = LOOSE_SCENES.get(name, (LSB_FRACTION, PSNR_DB))
     diff = np.abs(got["rgb"].astype(int) - want["rgb"].astype(int)).max(axis=2)
     frac = (diff <= 1).mean()
-    assert frac >= LSB_FRACTION, f"{name}: only {100 * frac:.3f}% of pixels within 1 LSB"
-    assert psnr(got["rgb"], want["rgb"]) >= PSNR_DB, name
+    assert frac >= lsb_fraction, f"{name}: only {100 * frac:.3f}% of pixels within 1 LSB"
+    assert psnr(got["rgb"], want["rgb"]) >= psnr_db, name
     bad_ids = int((got["hit_id"] != want["hit_id"]).sum())
     assert bad_ids <= hit_slack, f"{name}: {bad_ids} primary hit ids differ"
     assert got["counters"]["stack_overflows"] == 0
@@ -66,7 +79,12 @@ ALL_SCENES = ["basic_setup_scene", "white_sphere_one_light", "plane_test_1", "cu
               "monkey_3", "square_light_basic", "light_room", "subdivision_light", "scene_test_1", "scene_test_2", "scene_test_3",
               "scene_test_4", "scene_test_5", "refraction_03", "background_1", "many_balls", "many_balls_forest", "subtract_sphere",
               "many_weirds", "subtraction_room", "subtraction_outside1", "subtraction_outside3", "subtraction_outside4",
-              "rounded_cube", "xor_test", "reuleaux", "bump_map_basic_1", "octahedron_basic", "polyhedron_basic", "primitive_zoo"]
+              "rounded_cube", "xor_test", "reuleaux", "bump_map_basic_1", "octahedron_basic", "polyhedron_basic", "primitive_zoo",
+              # the rest of the reference's tests/*.rs, and the directional light no reference test uses
+              "octahedron_basic_02", "phong_test_1", "phong_test_2", "anti_alias_comparison", "scene_light_1_05", "translucent_shadow",
+              "bump_map_basic_2", "transparent_shapes", "transparent_orb", "normal_map_room_1", "normal_map_room_2", "texture_room",
+              "texture_cube", "skybox_test", "correlated_texture", "plane_texture", "dice_scene_lo_res", "dice_scene_hi_res",
+              "polygon_basic", "triangle_basic", "tetrahedron_basic", "direction_light_room"]
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
@@ -77,19 +95,22 @@ def test_scene_matches_oracle_with_aa(name, device_scene, scene_cache, oracle):
     want = oracle.render(s, dim, cam, cfg)
     slack = TIE_SCENES.get(name, 0)
     check(got, want, name, hit_slack=slack)
-    if slack == 0:
+    if slack == 0 and name not in LOOSE_SCENES:
         assert np.array_equal(got["aa_mask"], want["aa_mask"]), name
     # the unit of the benchmark metric is counted identically on both sides
     assert got["counters"]["rays_primary"] == want["counters"]["rays_primary"], name
-    if slack == 0:
+    if slack == 0 and name not in LOOSE_SCENES:
         assert got["counters"]["rays_aa"] == want["counters"]["rays_aa"], name
     total_g, total_o = got["counters"]["rays_total"], want["counters"]["rays_total"]
-    assert abs(total_g - total_o) <= max(2, total_o // 500), (name, total_g, total_o)
+    # (a tie pixel that goes the other way can flip an AA flag, and with it aa_rays whole ray trees)
+    assert abs(total_g - total_o) <= max(2, total_o // (200 if slack else 500)), (name, total_g, total_o)
 
 
 @pytest.mark.parametrize("name", ["basic_setup_scene", "light_room", "glass_monkey", "many_balls", "many_balls_forest",
                                   "subtraction_outside1", "subtraction_outside4", "primitive_zoo", "monkey_3", "xor_test",
-                                  "mesh_basic", "bump_map_basic_1", "polyhedron_basic", "scene_test_4", "background_1"])
+                                  "mesh_basic", "bump_map_basic_1", "polyhedron_basic", "scene_test_4", "background_1",
+                                  "direction_light_room", "dice_scene_lo_res", "texture_cube", "transparent_shapes", "normal_map_room_1",
+                                  "tetrahedron_basic"])
 def test_scene_matches_committed_golden(name, device_scene, scene_cache):
     s = scene_cache(name)
     dim, cam, cfg = small_view(s, 64, anti_alias=True, seed=1)

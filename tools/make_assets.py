@@ -28,6 +28,15 @@ IMAGES = [
     "backgrounds/sky_ocean.jpg",        # substitute for the missing forest2.jpg / building.jpg
     "backgrounds/room_lores.jpg",
     "tiny.png",
+    "textures/d8_num.png",              # octahedron_basic (tests/polyhedra_test.rs:90)
+    "textures/d6_num.png",              # dice_scene d6 (tests/dice_scene.rs:56)
+    "textures/d4_num.png",              # dice_scene d4, tetrahedron_basic (tests/dice_scene.rs:66)
+    "bump_maps/d6_num.png",             # dice_scene d6 bump map (tests/dice_scene.rs:53)
+    "textures/cube_rgb_numbers.png",    # texture_cube (tests/texture_test.rs:88)
+    "textures/keanu.jpg",               # plane_texture (tests/texture_test.rs:154); stands in for the 11 MB gurf-1.jpg
+    "textures/light_wood.jpg",          # dice_scene floor (tests/dice_scene.rs:33); stands in for the 35 MB wood_boards.jpg
+    "living_room.jpg",                  # skybox_test (tests/texture_test.rs:104)
+    "normal_maps/brick_wall_01.png",    # stands in for the missing normal_maps/brick_wall.jpg (src/util.rs:17)
 ]
 
 def convert(rel):
@@ -48,4 +57,5 @@ for m in ["monkey2.obj", "cube.obj"]:
     shutil.copyfile(os.path.join(REF, "assets/models", m), os.path.join(OUT, "models", m))
 gold = os.path.join(OUT, "..", "tests", "golden")
 os.makedirs(gold, exist_ok=True)
-shutil.copyfile(os.path.join(REF, "gallery/glass_monkey.png"), os.path.join(gold, "gallery_glass_monkey.png"))
+for g in ["glass_monkey", "light_room", "monkey_1"]:
+    shutil.copyfile(os.path.join(REF, f"gallery/{g}.png"), os.path.join(gold, f"gallery_{g}.png"))

@@ -14,7 +14,8 @@ from oracle import binding as orc
 SCENES = ["basic_setup_scene", "plane_test_1", "cube_test_1", "shadow_test_1", "child_transform_test_1",
           "light_room", "glass_monkey", "mesh_basic", "monkey_3", "many_balls", "many_balls_forest",
           "subtraction_outside1", "subtraction_outside4", "xor_test", "reuleaux", "bump_map_basic_1",
-          "octahedron_basic", "polyhedron_basic", "primitive_zoo", "scene_test_4", "background_1"]
+          "octahedron_basic", "polyhedron_basic", "primitive_zoo", "scene_test_4", "background_1",
+          "direction_light_room", "dice_scene_lo_res", "texture_cube", "transparent_shapes", "normal_map_room_1", "tetrahedron_basic"]
 WIDTH = 64
 
 def golden_view(scene):
