@@ -241,7 +241,9 @@ pub struct RtCounters {
     pub shade_evals: u64,
     pub stack_overflows: u64,
     pub flops: u64,
-    pub _reserved: [u64; 5],
+    pub schedule: u64,
+    pub attempts: u64,
+    pub _reserved: [u64; 3],
 }
 
 #[repr(C)]

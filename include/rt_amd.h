@@ -228,7 +228,11 @@ typedef struct RtCounters {
     uint64_t shade_evals;        /* Phong light evaluations (Lit illums)           */
     uint64_t stack_overflows;    /* rays dropped because a fixed stack was full (must be 0) */
     uint64_t flops;              /* algorithmic f64 flop estimate of the work above */
-    uint64_t _reserved[5];
+    uint64_t schedule;           /* which schedule rendered the frame: 1 ray queues in HBM (one launch
+                                    sequence per ray generation), 2 persistent kernel             */
+    uint64_t attempts;           /* frames enqueued for this call: 1, or more when a ray generation
+                                    outgrew the queues and the frame was redone with larger ones  */
+    uint64_t _reserved[3];
 } RtCounters;
 
 /* Optional per-pixel outputs, all W*H (row-major, top row first) or NULL.

@@ -51,7 +51,9 @@ class RtCounters(C.Structure):
         ("shade_evals", C.c_uint64),
         ("stack_overflows", C.c_uint64),
         ("flops", C.c_uint64),
-        ("_reserved", C.c_uint64 * 5),
+        ("schedule", C.c_uint64),
+        ("attempts", C.c_uint64),
+        ("_reserved", C.c_uint64 * 3),
     ]
 
     def as_dict(self):

@@ -128,6 +128,7 @@ struct RtScene {
     unsigned int dropped_seen = 0, dropped_reported = 0;
     uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
     bool last_used_queues = false, queue_overflowed = false;
+    int last_attempts = 1;                 // frames the most recent synchronous call enqueued
     bool last_noalloc = false;             // the most recent frame ran in the static scratch array: its queues cannot grow
     hipEvent_t ev_done = nullptr;          // after the last command of the most recent frame
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -659,6 +660,7 @@ bool note_drops(RtScene* s) {
 int render_complete_frame(RtScene* s, const RtImageDim& dim, const RtCamera& cam, const RtRenderConfig& cfg, uint8_t* d_rgb,
                           bool count, hipStream_t stream) {
     for (int attempt = 0; attempt < 8; ++attempt) {
+        s->last_attempts = attempt + 1;
         int rc = enqueue_frame(s, s->ws, dim, cam, cfg, d_rgb, count, stream);
         if (rc != RT_OK) return rc;
         s->last_noalloc = false;
@@ -714,6 +716,7 @@ int rt_render_device(const RtScene* scene, const RtImageDim* dim, const RtCamera
             HIP_TRY(hipStreamSynchronize(stream));
             c.aa_pixels = aa;
             fill_counters(d_aux->counters, c);
+            d_aux->counters.schedule = s->last_used_queues ? 1 : 2; d_aux->counters.attempts = (uint64_t)s->last_attempts;
         }
     }
     return RT_OK;
@@ -808,6 +811,7 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             HIP_TRY(hipMemcpy(&aa, static_cast<char*>(s->ws.scalars.p) + SC_AA_COUNT * 4, sizeof aa, hipMemcpyDeviceToHost));
             c.aa_pixels = aa;
             fill_counters(aux->counters, c);
+            aux->counters.schedule = s->last_used_queues ? 1 : 2; aux->counters.attempts = (uint64_t)s->last_attempts;
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work) {   // lane occupancy of the trace kernel's phases
             DCounters c{};
