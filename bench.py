@@ -41,10 +41,10 @@ sys.path.insert(0, ROOT)
 # name -> (scene, width, height, config overrides, CPU sample: every n-th row block); the first is BASELINE.json's metric configuration
 CONFIGS = {
     "glass_monkey": ("glass_monkey", 1920, 1080, {}, 3),
-    "light_room": ("light_room", 1920, 1080, {}, 16),
-    "many_balls_forest": ("many_balls_forest", 3840, 2160, {}, 8),
-    "subtraction_outside": ("subtraction_outside1", 3840, 2160, {}, 8),
-    "subtraction_outside_ss": ("subtraction_outside1", 3840, 2160, {"aa_threshold": 0.0}, 16),   # supersampled: every interior hit pixel gets aa_rays more
+    "light_room": ("light_room", 1920, 1080, {}, 2),
+    "many_balls_forest": ("many_balls_forest", 3840, 2160, {}, 4),
+    "subtraction_outside": ("subtraction_outside1", 3840, 2160, {}, 2),
+    "subtraction_outside_ss": ("subtraction_outside1", 3840, 2160, {"aa_threshold": 0.0}, 3),   # supersampled: every interior hit pixel gets aa_rays more
 }
 TILE_ROWS = 8     # rows per block of the multi-GPU split (measured on 1080p: 8 balances the ranks best; 4 pays too much halo)
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, FP64 vector with FMA (half the 157.3 TF FP32 vector rate)

@@ -97,14 +97,14 @@ struct Workspace {
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
     DeviceBuf queue[2], acc, acc_flags, lane_mem;
     // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
-    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_overflow, wf_scalars;
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars;
     uint32_t wf_cap = 0;
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     std::vector<DeviceBuf*> all() {
         return {&color, &distance, &hit_id, &mask, &list, &samples, &rows, &scalars, &rgb_full, &queue[0], &queue[1], &acc, &acc_flags, &lane_mem,
-                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_contrib, &wf_walk_list, &wf_overflow, &wf_scalars};
+                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_contrib, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars};
     }
     void use(Arena* a) { for (DeviceBuf* b : all()) b->arena = a; }
     void release() { for (DeviceBuf* b : all()) b->release(); }
@@ -301,7 +301,8 @@ constexpr size_t WF_CAP_MAX = (size_t)1 << 26;      // entries per queue array
 constexpr uint32_t WF_N = 0, WF_WALK_COUNT = WF_N + 2 * RT_WF_Q * (WF_MAX_GEN + 1), WF_WALK_NEXT = WF_WALK_COUNT + RT_WF_Q * (WF_MAX_GEN + 1),
                    WF_PASS_WORDS = WF_WALK_NEXT + RT_WF_Q * (WF_MAX_GEN + 1);
 constexpr uint32_t WF_HIT_COUNT = 2 * WF_PASS_WORDS;            // per pass 2 * RT_WF_Q * (WF_MAX_GEN + 1) words
-constexpr size_t WF_SCALAR_BYTES = (WF_HIT_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1) + 4) * 4;
+constexpr uint32_t WF_CSG_COUNT = WF_HIT_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1);   // per pass 2 * RT_WF_Q * (WF_MAX_GEN + 1) words
+constexpr size_t WF_SCALAR_BYTES = (WF_CSG_COUNT + 2 * 2 * RT_WF_Q * (WF_MAX_GEN + 1) + 4) * 4;
 // RT_PATH=persistent forces the persistent kernel for every scene (read at every frame, so that a
 // test can render the same scene down both schedules in one process).
 bool use_wavefront(uint32_t features) {
@@ -432,7 +433,8 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     const uint32_t walk_cus_max = fixed_mem ? std::min(128u, (uint32_t)s->num_cus) : (uint32_t)s->num_cus;
     const size_t walk_overflow_bytes = (size_t)(fixed_mem ? 1u : 4u) * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4u;   // per chain: a walk launch with up to 2048 threads per CU
     const size_t wf_entry_bytes = 2 * (RQ_NF * 8 + RQ_NU * 4) + 2 * (SQ_NF * 8 + SQ_NU * 4) + 2 * (JQ_NF * 8 + JQ_NU * 4) +
-                                  (s->ds.has_background ? CQ_NF * 8 + CQ_NU * 4 : 0) + 2 * sizeof(uint32_t);
+                                  (s->ds.has_background ? CQ_NF * 8 + CQ_NU * 4 : 0) + 2 * sizeof(uint32_t) +
+                                  ((s->ds.features & RTF_CSG) ? 2 * sizeof(uint32_t) : 0);
     // queue pipeline: s->wf_scale entries per pixel (and queue) of this rank's share, every queue cut into RT_WF_Q sub-queues
     uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)W * num_rows * s->wf_scale, 1u << 20), WF_CAP_MAX);
     if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, (long)WF_CAP_MAX); }   // tests: provoke an overflow
@@ -531,6 +533,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         if ((e = w.wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if (s->ds.has_background && (e = w.wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
+        if ((s->ds.features & RTF_CSG) && (e = w.wf_csg_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
         if ((e = w.wf_overflow.ensure(walk_overflow_bytes)) != RT_OK) return e;
         if ((e = w.wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
         HIP_TRY(hipMemsetAsync(w.wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
@@ -538,6 +541,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
         wa.rjobs = queue(w.wf_rjobs, n, JQ_NF); wa.sjobs = queue(w.wf_sjobs, n, JQ_NF);
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
+        wa.csg_list = (uint32_t*)w.wf_csg_list.p;
         wa.walk_list = (uint32_t*)w.wf_walk_list.p; wa.walk_overflow = (uint32_t*)w.wf_overflow.p; wa.refill_min = std::getenv("RT_REFILL_MIN") ? refill_min() : 24u; wa.descend_frac = descend_frac();   // (measured: 24 free lanes before the walk kernel refills, 16 in the persistent kernel)
         wa.contrib = queue(w.wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)w.acc.p; wa.acc_flags = (uint32_t*)w.acc_flags.p;
@@ -569,6 +573,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
             wa.rays = queue(w.wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(w.wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
             wa.out_rays = queue(w.wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
             wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g;
+            wa.csg_count = (unsigned int*)w.wf_scalars.p + WF_CSG_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             wa.hit_count = (unsigned int*)w.wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             for (uint32_t c = 0; c < chains; ++c) {
                 hipStream_t cs = c == 0 ? stream : s->chain_stream[c - 1];
@@ -585,6 +590,10 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                 const uint32_t cgrid = grid / chains;
                 int lrc = wf_launch(0, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
+                if (s->ds.features & RTF_CSG) {                          // the queries that reach a composite shape
+                    lrc = wf_launch(3, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    if (lrc != RT_OK) return lrc;
+                }
                 if (s->ds.features & RTF_MESH) {
                     lrc = wf_launch_walk(count_work, cus, cs, s->ds, wa);
                     if (lrc != RT_OK) return lrc;

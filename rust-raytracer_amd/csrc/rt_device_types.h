@@ -126,6 +126,7 @@ struct DCsgLeaf {
 };
 struct DCsgRoot {
     uint32_t op_begin, op_count;
+    uint32_t leaf_begin, num_leaves;   // its leaves are consecutive in csg_leaves[], in the order of their BASE ops
     // box around all leaves in the composite's own space (bounded == 0: some leaf is infinite): a ray that
     // misses it hits no leaf, so every hit list is empty and the composite has no hit either
     uint32_t bounded, _pad;

@@ -649,6 +649,7 @@ private:
                 const size_t leaf0 = fs_.csg_leaves.size();
                 csg(p.ref, identity(), identity(), 0, lists);
                 root.op_count = (uint32_t)fs_.csg_ops.size() - root.op_begin;
+                root.leaf_begin = (uint32_t)leaf0; root.num_leaves = (uint32_t)(fs_.csg_leaves.size() - leaf0);
                 {   // box around the leaves, padded like the instance boxes of the top-level tree
                     const double inf = std::numeric_limits<double>::infinity();
                     V3 wlo{inf, inf, inf}, whi{-inf, -inf, -inf};

@@ -834,6 +834,105 @@ RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, C
     out.b = ((h.meta >> 1) & 1u) | (((h.meta >> 2) & 1u) << 1) | ((h.meta >> 8) << 8);
     return true;
 }
+// ---- the same answer without lists, for the common case
+// With every event (leaf hit) at a distance of its own, each predicate of csg_predicate says exactly
+// "the value of this node's set operation changes here" (Subtract: P and not N, And, Or, Xor,
+// MultiAnd), a child's initial state "its first event is an exit" says "the ray starts inside it",
+// and an emitted event enters the composite iff that value becomes true.  So the closest hit of the
+// whole tree is the first event, in order of distance, at which the root's value - a boolean
+// expression of the leaves' inside bits - changes; its normal is inverted iff the leaf hit and the
+// root disagree about entering.  That needs no hit lists (the generic machine keeps them in
+// scratch memory, where lanes with different list lengths hit different cache lines with every
+// access): leaf events in registers, one bit of state per leaf.  Returns 0: no hit, 1: hit,
+// 2: not applicable - equal distances (their order of processing matters), a leaf whose two hits do
+// not alternate between entering and leaving, or more than RT_CSG_FAST_LEAVES leaves - in which
+// case the caller runs the generic machine.
+#define RT_CSG_FAST_LEAVES 4
+RT_DEV bool csg_value(const DScene& sc, const DCsgRoot& root, uint32_t inside_bits) {
+    uint32_t stk = 0;                                              // a stack of booleans, top in bit 0
+    for (uint32_t oi = 0; oi < root.op_count; ++oi) {
+        const DCsgOp& op = sc.csg_ops[root.op_begin + oi];
+        if (op.kind == DC_BASE) { stk = (stk << 1) | ((inside_bits >> (op.leaf - root.leaf_begin)) & 1u); continue; }
+        if (op.kind == DC_MULTI_AND) {
+            const uint32_t k = op.num_children, all = (1u << k) - 1u;
+            stk = ((stk >> k) << 1) | ((stk & all) == all ? 1u : 0u);
+            continue;
+        }
+        const uint32_t b = stk & 1u, a = (stk >> 1) & 1u;          // children in order: a below b
+        uint32_t v;
+        switch (op.kind) {
+            case DC_SUBTRACT: v = a & (b ^ 1u); break;
+            case DC_AND: v = a & b; break;
+            case DC_OR: v = a | b; break;
+            default: v = a ^ b; break;                             // DC_XOR
+        }
+        stk = ((stk >> 2) << 1) | v;
+    }
+    return (stk & 1u) != 0u;
+}
+template <uint32_t F, bool COUNT>
+RT_DEV int csg_closest_fast(const DScene& sc, const DCsgRoot& root, const LRay& r, Cand& out, Work<COUNT>& wk) {
+    constexpr int L = RT_CSG_FAST_LEAVES;
+    if (root.num_leaves > (uint32_t)L) return 2;
+    double et[2 * L];                                              // event distances in the composite's parent space (+inf: none)
+    uint32_t em[2 * L];                                            // bit 0: enters its leaf, bit 2: the leaf candidate's b bit 0
+    uint32_t inside_bits = 0;
+    bool odd = false;
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) { et[k] = INFINITY; em[k] = 0; }
+    for (uint32_t j = 0; j < root.num_leaves; ++j) {               // BaseShape::get_all_intersects, base_shape.rs:49-53
+        const DCsgLeaf& leaf = sc.csg_leaves[root.leaf_begin + j];
+        const DPrim& p = sc.prims[leaf.prim];
+        double s, inv_s;
+        LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
+        Cand c[2];
+        int n = basic_hits<F, COUNT>(sc, p, lr, INFINITY, c, wk);
+        if constexpr (F & RTF_WRAP) { if (p.wrap) n = wrap_all<F>(sc, p, lr, c, n); }
+        double t0 = INFINITY, t1 = INFINITY;
+        uint32_t m0 = 0, m1 = 0;
+        bool enter0 = false;
+        if (n > 0) {
+            enter0 = facing<F>(sc, p, lr, c[0]) < 0.0;                // hit_direction, composite_shape.rs:27-30
+            t0 = c[0].t * inv_s; m0 = (enter0 ? 1u : 0u) | ((c[0].b & 1u) << 2);
+            if (!enter0) inside_bits |= 1u << j;                   // initial inside-state from the first hit, :99-109
+        }
+        if (n > 1) {
+            const bool enter1 = facing<F>(sc, p, lr, c[1]) < 0.0;
+            t1 = c[1].t * inv_s; m1 = (enter1 ? 1u : 0u) | ((c[1].b & 1u) << 2);
+            if (enter1 == enter0) odd = true;
+        }
+#pragma unroll
+        for (int k = 0; k < L; ++k)                                 // (register arrays: written by selection, never by a run-time index)
+            if ((uint32_t)k == j) { et[2 * k] = t0; et[2 * k + 1] = t1; em[2 * k] = m0; em[2 * k + 1] = m1; }
+    }
+    if (odd) return 2;
+    bool value = csg_value(sc, root, inside_bits);
+    double last = -INFINITY;
+    for (int step = 0; step < 2 * L; ++step) {
+        double mt = INFINITY;
+        uint32_t mk = 0, mm = 0, same = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * L; ++k) {
+            const bool take = et[k] > last && et[k] < mt;
+            same = take ? 0u : (et[k] == mt && et[k] < INFINITY ? same + 1u : same);
+            mk = take ? (uint32_t)k : mk; mm = take ? em[k] : mm; mt = take ? et[k] : mt;
+        }
+        if (!(mt < INFINITY)) return 0;
+        if (same) return 2;                                        // two events at one distance
+        inside_bits ^= 1u << (mk >> 1);
+        const bool now = csg_value(sc, root, inside_bits);
+        if (now != value) {
+            const uint32_t inverted = ((mm & 1u) != 0u) != now ? 1u : 0u;
+            out.t = mt;
+            out.a = root.leaf_begin + (mk >> 1);
+            out.b = inverted | (((mm >> 2) & 1u) << 1) | ((mk & 1u) << 8);
+            return 1;
+        }
+        last = mt;
+    }
+    return 0;
+}
+
 template <uint32_t F, bool COUNT>
 RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details& o, Work<COUNT>& wk) {
     const DCsgLeaf& leaf = sc.csg_leaves[c.a];
@@ -861,8 +960,10 @@ struct SceneHit {
     Cand c;              // in the instance's primitive space
 };
 
-template <uint32_t F, bool COUNT>
-RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk) {
+// WITH_CSG = false: composite shapes are not evaluated; a composite whose bounding box the ray reaches is
+// reported in *deferred (bit min(root index, 31)) for the caller to answer elsewhere, and counts as a miss here.
+template <uint32_t F, bool COUNT, bool WITH_CSG = true>
+RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk, uint32_t* deferred = nullptr) {
     if constexpr (F & RTF_CSG) {
         if (p.kind == DP_CSG) {
             const DCsgRoot& root = sc.csg_roots[p.ref];
@@ -870,7 +971,14 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
                 double tn;
                 if (!slab(root.lo, root.hi, lr.o, mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z), INFINITY, tn)) return false;
             }
-            return csg_closest<F, COUNT>(sc, root, lr, c, wk);
+            if constexpr (WITH_CSG) {
+                const int fast = csg_closest_fast<F, COUNT>(sc, root, lr, c, wk);
+                if (fast != 2) return fast == 1;
+                return csg_closest<F, COUNT>(sc, root, lr, c, wk);
+            } else {
+                *deferred |= 1u << min(p.ref, 31u);
+                return false;
+            }
         }
     }
     Cand cc[2];
@@ -893,8 +1001,8 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
 // Scenes with many instances carry a BVH over the instances' world-space boxes (RTF_TLAS); the
 // reference tests every child of a node in turn (src/scene.rs:205-217), which only fixes the
 // winner among equal distances: the earlier instance, kept here by an explicit tie rule.
-template <uint32_t F, bool COUNT, bool SKIP_MESH>
-RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk) {
+template <uint32_t F, bool COUNT, bool SKIP_MESH, bool WITH_CSG = true>
+RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk, uint32_t* deferred = nullptr) {
     bool found = false;
     double best = any ? max_distance : INFINITY;
     // one instance; returns true when an any-hit query is settled
@@ -917,7 +1025,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
                 if (any) return got;
             }
         } else {
-            got = prim_closest<F, COUNT>(sc, p, lr, any ? INFINITY : best * s, c, wk);
+            got = prim_closest<F, COUNT, WITH_CSG>(sc, p, lr, any ? INFINITY : best * s, c, wk, deferred);
             if (any) return got && (in.is_root ? c.t <= max_distance * s : c.t < max_distance * s);
         }
         if (!got) return false;

@@ -32,7 +32,7 @@ struct LaunchStatus {             // hipSuccess, or the failing call
     LaunchStatus rt_launch_trace_##name(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta);
 RT_TRACE_VARIANTS(RT_DECLARE_TRACE)
 #undef RT_DECLARE_TRACE
-// which: 0 analytic, 1 shade, 2 settle
+// which: 0 analytic, 1 shade, 2 settle, 3 analytic redo (scenes with composite shapes)
 #define RT_DECLARE_WF(name, F) \
     LaunchStatus rt_launch_wf_##name(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa);
 RT_WF_VARIANTS(RT_DECLARE_WF)
@@ -62,12 +62,17 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
     uint32_t lds = tables;
     if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
     if (which == 2) lds = 4u * 640u * 8u;
-    const void* fn;
-    if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true> : (const void*)k_wf_analytic<F, false, true>)
-                             : (count ? (const void*)k_wf_analytic<F, true, false> : (const void*)k_wf_analytic<F, false, false>);
+    const void* fn = nullptr;
+    if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, false> : (const void*)k_wf_analytic<F, false, true, false>)
+                             : (count ? (const void*)k_wf_analytic<F, true, false, false> : (const void*)k_wf_analytic<F, false, false, false>);
     else if (which == 1) fn = hot ? (count ? (const void*)k_wf_shade<F, true, true> : (const void*)k_wf_shade<F, false, true>)
                                   : (count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>);
-    else fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
+    else if (which == 2) fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
+    else if constexpr ((F & RTF_CSG) != 0) {                            // 3: the analytic kernel's second run (composite shapes only)
+        fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, true> : (const void*)k_wf_analytic<F, false, true, true>)
+                 : (count ? (const void*)k_wf_analytic<F, true, false, true> : (const void*)k_wf_analytic<F, false, false, true>);
+    }
+    if (!fn) return {hipErrorInvalidValue, "queue-pipeline kernel selection"};
     if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);

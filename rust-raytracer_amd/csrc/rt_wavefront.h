@@ -97,6 +97,11 @@ struct WfArgs {
     // its walk list (free again after the walk); materials that spawn no rays from the front, the
     // others from the back; hit_count[2s], hit_count[2s+1] (one 64-bit word) count the two kinds
     unsigned int* hit_count;
+    // composite shapes: queries whose ray reaches the bounding box of a composite, per sub-queue a list of 2*sub
+    // query ids (encoded like the walk list's) - those that reach only the scene's first composite from the front,
+    // the others from the back - and csg_count[2s], csg_count[2s+1]; a second run of the analytic kernel answers them
+    uint32_t* csg_list;
+    unsigned int* csg_count;
     uint32_t* walk_overflow;          // (RT_BVH_STACK - RT_WF_LDS_STACK) words per walk thread
     uint32_t refill_min;
     uint32_t descend_frac;            // eighths: the descent pauses for the leaves once fewer than this share of the walking lanes still descend (0: never)
@@ -240,30 +245,52 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 
 // ------------------------------------------------------------------ analytic phase
 // One thread per queue entry: the sub-queue's rays first, then its shadow tests.
+// Scenes with composite shapes run it twice.  REDO = false: every entry, composites left out; a query
+// whose ray reaches a composite's bounding box is listed instead of answered.  REDO = true: the listed
+// queries only, composites included.  The composite evaluation is by far the heaviest part of a query
+// and differs from composite to composite (four spheres, a cube and a sphere, ...): listed side by
+// side, queries with the same work fill whole waves, and the first run keeps neither its registers
+// nor its scratch memory.
 // LDS: [small scene tables]
-template <uint32_t F, bool COUNT, bool HOT>
+template <uint32_t F, bool COUNT, bool HOT, bool REDO>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
+    constexpr bool HAS_CSG = (F & RTF_CSG) != 0;
+    static_assert(HAS_CSG || !REDO, "only scenes with composite shapes have anything to redo");
     const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t nr = min(a.n_in[2 * sq], a.sub), nsh = min(a.n_in[2 * sq + 1], a.sub);
-    if ((blockIdx.x / a.sq_count) * blockDim.x >= nr + nsh) return;     // nothing for this workgroup: leave before the tables are copied
+    const uint32_t n0 = REDO ? min(a.csg_count[2 * sq], 2u * a.sub) : 0u, n1 = REDO ? min(a.csg_count[2 * sq + 1], 2u * a.sub - n0) : 0u;
+    const uint32_t r0 = (n0 + 63u) & ~63u;                            // the second kind starts in a wave of its own
+    const uint32_t nwork = REDO ? r0 + n1 : nr + nsh;
+    if ((blockIdx.x / a.sq_count) * blockDim.x >= nwork) return;        // nothing for this workgroup: leave before the tables are copied
     const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     const uint32_t cap = a.cap;
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
-    for (uint32_t ql = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; ql < nr + nsh; ql += (gridDim.x / a.sq_count) * blockDim.x) {
-        if (ql < nr) {
-            const uint32_t q = sq * a.sub + ql;
-            if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
-            if (a.rays.U(cap, RQ_FLAGS, q) & 8u) { a.rjobs.U(cap, JQ_FLAGS, q) = 6u; continue; }        // a hole (queue overflow only)
-        } else {
-            const uint32_t q = sq * a.sub + ql - nr;
-            if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { a.sjobs.U(cap, JQ_FLAGS, q) = 7u; continue; }   // a hole
+    const uint32_t* clist = a.csg_list + (size_t)sq * (2u * a.sub);
+    for (uint32_t wi = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; wi < nwork; wi += (gridDim.x / a.sq_count) * blockDim.x) {
+        uint32_t ql = wi;
+        if constexpr (REDO) {
+            if (wi >= n0 && wi < r0) continue;
+            const uint32_t e = wi < n0 ? clist[wi] : clist[2u * a.sub - 1u - (wi - r0)];
+            ql = (e & 0x80000000u) ? nr + (e & 0x7FFFFFFFu) - sq * a.sub : e - sq * a.sub;
+        }
+        if (!REDO) {
+            if (ql < nr) {
+                const uint32_t q = sq * a.sub + ql;
+                if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
+                if (a.rays.U(cap, RQ_FLAGS, q) & 8u) { a.rjobs.U(cap, JQ_FLAGS, q) = 6u; continue; }        // a hole (queue overflow only)
+            } else {
+                const uint32_t q = sq * a.sub + ql - nr;
+                if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { a.sjobs.U(cap, JQ_FLAGS, q) = 7u; continue; }   // a hole
+            }
         }
         const bool shadow = ql >= nr;
         const uint32_t q = sq * a.sub + (shadow ? ql - nr : ql);      // entry of the shadow-test / ray arrays
         const WfQueue& jobs = shadow ? a.sjobs : a.rjobs;
+        const Work<COUNT> wk_before = wk;                             // (a query handed to the second run is counted there)
+        const unsigned long long cam_before = cam;
         d3 o, d;
         double max_distance = 0.0;
         if (shadow) {
@@ -274,7 +301,8 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
             o = a.rays.ld3(cap, RQ_O, q); d = a.rays.ld3(cap, RQ_D, q);
             const d3 rc = a.rays.ld3(cap, RQ_C, q);
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
-            if (!(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
+            // (a listed query has passed it already)
+            if (!REDO && !(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
                 const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
                 // its colour term: the background (k_wf_accumulate adds it); exactly nothing without a sky box
                 if (sc.has_background) {
@@ -289,7 +317,18 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         }
         SceneHit h;
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
-        bool found = trace_scene<F, COUNT, HAS_MESH>(sc, o, d, shadow, max_distance, h, wk);
+        uint32_t deferred = 0;
+        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred);
+        if constexpr (HAS_CSG && !REDO) {
+            if (deferred && !(shadow && found)) {                     // (an occluded shadow test needs no composite any more)
+                wk = wk_before; cam = cam_before;                     // its record is written, and its work counted, by the second run
+                uint32_t* list = a.csg_list + (size_t)sq * (2u * a.sub);
+                const uint32_t e = shadow ? (q | 0x80000000u) : q;
+                if (deferred == 1u) list[wave_alloc(a.csg_count + 2 * sq)] = e;
+                else list[2u * a.sub - 1u - wave_alloc(a.csg_count + 2 * sq + 1)] = e;
+                continue;
+            }
+        }
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
         jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
         jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
