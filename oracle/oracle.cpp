@@ -1087,9 +1087,16 @@ struct SquareLight : Lightable {                                            // :
     static constexpr size_t SUB_DEPTH = 5;                                  // :187
     Color get_intensity(double d) const { return color * power / (4.0 * PI * d * d); }   // :365-368
 
-    struct Rng {   // replaces thread_rng: draw #counter of (stream, path, light)
-        uint64_t stream; uint32_t path, light, counter;
-        double gen_range(double lo, double hi) { return lo + (hi - lo) * rng_light(stream, path, light, counter++); }
+    // Replaces thread_rng.  A draw is identified by where it is made, not by how many came before it:
+    // quadrant `node` of the subdivision tree (level by level, root 0, the four children of the quadrant with
+    // position code k at one level have codes 4k..4k+3 at the next, in the order they are visited) makes draws
+    // 0..7 for its four jittered probes and draws 8.. for the samples that fill it.  The tree can then be
+    // walked in any order, by any number of workers, with the same result.
+    struct Rng {
+        uint64_t stream; uint32_t path, light, node, local;
+        static uint32_t node_of(uint32_t level, uint32_t code) { return ((1u << (2 * level)) - 1u) / 3u + code; }
+        uint32_t next() { return node * 2048u + local++; }
+        double gen_range(double lo, double hi) { return lo + (hi - lo) * rng_light(stream, path, light, next()); }
     };
     void subdivide_points(V2 min, V2 max, Rng& rng, V3 out[4]) const {      // :189-219
         V2 change = max - min;
@@ -1107,8 +1114,10 @@ struct SquareLight : Lightable {                                            // :
         size_t num_illums = (size_t)1 << (2 * depth);
         area_porp = 4.0 * area_porp / (double)num_illums;
         for (size_t i = 0; i < num_illums; ++i) {
-            double sx = rng.gen_range(min.x, max.x);
-            double sz = rng.gen_range(min.y, max.y);
+            double u, v;                                                     // one draw for the pair (:229-230 draws twice)
+            rng_light_pair(rng.stream, rng.path, rng.light, rng.next(), u, v);
+            double sx = min.x + (max.x - min.x) * u;
+            double sz = min.y + (max.y - min.y) * v;
             V3 point = position + v3(sx, 0.0, sz);
             V3 hit_to_light = point - it.hit_point;
             double light_distance = length(hit_to_light);
@@ -1117,7 +1126,8 @@ struct SquareLight : Lightable {                                            // :
             out.push_back({true, surface_dot, light_direction, get_intensity(light_distance) * area_porp});
         }
     }
-    void subdivide_illumination(V2 min, V2 max, const Scene& scene, const Intersect& it, size_t depth, Rng& rng, std::vector<Illum>& out) const {   // :248-298
+    void subdivide_illumination(V2 min, V2 max, const Scene& scene, const Intersect& it, size_t depth, uint32_t code, std::vector<Illum>& out) const {   // :248-298
+        Rng rng{it.ray.stream, it.ray.path, index, Rng::node_of((uint32_t)(SUB_DEPTH - depth), code), 0};
         Illum sample_illums[4];
         V3 sample_points[4];
         subdivide_points(min, max, rng, sample_points);
@@ -1140,17 +1150,16 @@ struct SquareLight : Lightable {                                            // :
             V2 change = (max - min) * 0.5;
             V2 left{min.x, min.y + change.y}, mid = min + change, right{max.x, max.y - change.y};
             V2 top{max.x - change.x, max.y}, bot{min.x + change.x, min.y};
-            subdivide_illumination(left, top, scene, it, depth - 1, rng, out);
-            subdivide_illumination(mid, max, scene, it, depth - 1, rng, out);
-            subdivide_illumination(min, mid, scene, it, depth - 1, rng, out);
-            subdivide_illumination(bot, right, scene, it, depth - 1, rng, out);
+            subdivide_illumination(left, top, scene, it, depth - 1, 4 * code + 0, out);
+            subdivide_illumination(mid, max, scene, it, depth - 1, 4 * code + 1, out);
+            subdivide_illumination(min, mid, scene, it, depth - 1, 4 * code + 2, out);
+            subdivide_illumination(bot, right, scene, it, depth - 1, 4 * code + 3, out);
         }
     }
     std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const override {   // :370-374
         double half_size = size * 0.5;
-        Rng rng{it.ray.stream, it.ray.path, index, 0};
         std::vector<Illum> out;
-        subdivide_illumination({-half_size, -half_size}, {half_size, half_size}, scene, it, SUB_DEPTH, rng, out);
+        subdivide_illumination({-half_size, -half_size}, {half_size, half_size}, scene, it, SUB_DEPTH, 0, out);
         return out;
     }
 };

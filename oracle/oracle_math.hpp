@@ -199,6 +199,12 @@ inline double rng_light(uint64_t stream, uint32_t path, uint32_t light, uint32_t
     return u01(sm64(stream ^ (((uint64_t)path << 32) | ((uint64_t)(light & 0x3FFu) << 22) | (uint64_t)(counter & 0x3FFFFFu))));
 }
 // AA draws of a pixel: index 0 = rotation, 1+i = radius of ray i
+// one draw, two uniforms (upper and lower 32 bits): the coordinates of an unshadowed light sample
+inline void rng_light_pair(uint64_t stream, uint32_t path, uint32_t light, uint32_t counter, double& u, double& v) {
+    const uint64_t h = sm64(stream ^ (((uint64_t)path << 32) | ((uint64_t)(light & 0x3FFu) << 22) | (uint64_t)(counter & 0x3FFFFFu)));
+    u = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
+    v = (double)(uint32_t)h * (1.0 / 4294967296.0);
+}
 inline double rng_aa(uint64_t stream0, uint32_t index) { return u01(sm64(stream0 ^ (0xA5A5A5A500000000ull + index))); }
 
 }  // namespace orc

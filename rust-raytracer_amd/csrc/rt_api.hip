@@ -232,7 +232,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
         s->lds_limit = lds_max > 0 ? (uint32_t)lds_max : 65536u;
         d.lds_blob = nullptr; d.lds_blob_bytes = 0;
-        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + std::max<size_t>(RT_LDS_FIXED_BYTES(512u), RT_WF_WALK_FIXED_BYTES(1024u)) <= s->lds_limit) {
+        if ((fs.features & RTF_MESH) && fs.lds_exact && !fs.lds_blob.empty() && fs.lds_blob.size() + std::max<size_t>(RT_LDS_FIXED_BYTES(512u) + ((fs.features & RTF_INLINE_LIGHTS) ? RT_AREA_LDS_BYTES(8u) : 0u), RT_WF_WALK_FIXED_BYTES(1024u)) <= s->lds_limit) {
             rc = upload(fs.lds_blob, s->owned, &d.lds_blob);
             if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
             d.lds_blob_bytes = (uint32_t)fs.lds_blob.size();
@@ -323,6 +323,10 @@ uint32_t idle_divisor() {
     return d;
 }
 
+uint32_t trace_waves_per_cu() {   // waves of the persistent kernel per CU (kernel tuning experiments)
+    static const uint32_t w = [] { const char* e = std::getenv("RT_TRACE_WAVES_PER_CU"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min<long>(v, 32) : 8u; }();
+    return w;
+}
 uint32_t batch_limit() {
     static const uint32_t b = [] { const char* e = std::getenv("RT_BATCH_LIMIT"); long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min<long>(v, RT_BATCH) : 4u; }();
     return b;
@@ -472,7 +476,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
 
     // persistent grid: enough waves to fill every CU several times over; each pulls tiles until none are left
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
-    const uint32_t max_waves = (uint32_t)s->num_cus * 8;           // two waves per SIMD: all the register file allows
+    const uint32_t max_waves = (uint32_t)s->num_cus * trace_waves_per_cu();   // default: two waves per SIMD, all the register file allows
     if (!wavefront && (e = w.lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
     HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit

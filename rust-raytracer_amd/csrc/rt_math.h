@@ -72,4 +72,45 @@ RT_DEV uint32_t child_path(uint32_t parent, uint32_t ordinal) { return hash32(pa
 RT_DEV double rng_light(uint64_t stream, uint32_t path, uint32_t light, uint32_t counter) {
     return u01(sm64(stream ^ (((uint64_t)path << 32) | ((uint64_t)(light & 0x3FFu) << 22) | (uint64_t)(counter & 0x3FFFFFu))));
 }
+// One draw that yields two uniforms (its upper and lower 32 bits): the pair of coordinates of a
+// light sample that is taken without a shadow test.
+RT_DEV void rng_light_pair(uint64_t stream, uint32_t path, uint32_t light, uint32_t counter, double& u, double& v) {
+    const uint64_t h = sm64(stream ^ (((uint64_t)path << 32) | ((uint64_t)(light & 0x3FFu) << 22) | (uint64_t)(counter & 0x3FFFFFu)));
+    u = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
+    v = (double)(uint32_t)h * (1.0 / 4294967296.0);
+}
 RT_DEV double rng_aa(uint64_t stream0, uint32_t index) { return u01(sm64(stream0 ^ (0xA5A5A5A500000000ull + index))); }
+
+// ---- IEEE division and square root without the range scaling of the general sequences ----
+// x / d is what the compiler's f64 division computes (reciprocal estimate, two Newton steps,
+// quotient, one correction with the exact remainder) when neither operand needs the exponent
+// scaling of v_div_scale, i.e. for d and x well inside the normal range; the result is then the
+// correctly rounded quotient, bit for bit the same as `x / d`.  Splitting it lets several
+// quotients by one divisor share the reciprocal.  Callers check the divisor's range
+// (nr_in_range) and take the general path otherwise.
+RT_DEV double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+RT_DEV double div_nr(double x, double d, double rcp_d) {
+    const double q = x * rcp_d;
+    const double rem = __builtin_fma(-d, q, x);
+    return __builtin_fma(rem, rcp_d, q);
+}
+// sqrt(x) as the compiler's f64 sequence computes it for x in the normal range (no scaling of
+// tiny arguments, no zero / infinity pass-through).
+RT_DEV double sqrt_nr(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+RT_DEV bool nr_in_range(double x) { return (int)(fabs(x) > 0x1p-200) & (int)(fabs(x) < 0x1p200); }

@@ -163,18 +163,29 @@ RT_DEV bool occluded(const DScene& sc, d3 o, d3 d, double max_distance, Work<COU
     return trace_scene<F, COUNT, false>(sc, o, d, true, max_distance, h, wk);
 }
 
-// SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374) with
-// an explicit stack of quadrants.  Quadrants are visited in the reference's depth-first
-// order so that the draw counter of the RNG advances identically.
+// SquareLight::get_illums_at → subdivide_illumination (src/light.rs:248-298, 370-374).
 //
-// A quadrant whose four probes are all lit is filled with 4^depth unshadowed samples
-// (guess_illums, :222-245), up to 1024 Phong terms for one hit: by far the largest piece of work
-// of an area-lit scene, and one lane's alone.  Here the lanes that entered this function
-// together stay in its loop until all of them are done, and every such batch of samples is
-// spread over all of them: the random draws are counter-based, so sample i can be evaluated by
-// any lane, and the terms are summed in fixed point (integer limbs, like the frame's
-// accumulators), so the sum does not depend on which lanes helped.  It differs from the
-// reference's left-to-right f64 sum by rounding only (relative 1e-16 per term).
+// The reference walks a quadtree over the light, depth first and one hit at a time: four jittered,
+// shadow-tested probes per quadrant, then either their Phong terms (deepest level, or all four
+// dark), 4^depth untested samples in their place (all four lit: guess_illums, :222-245), or the four
+// child quadrants.  A hit in a penumbra visits up to 341 quadrants, its neighbours one, so a wave
+// that gives each lane its own hit idles most of its lanes.  Here the lanes that reach this
+// function together share ALL the work of their hits, level by level:
+//   - every lane keeps the quadrants of its own hit at the current level as a bit set (position
+//     code within the level: two bits per ancestor);
+//   - round by round, as many quadrants as the wave has lanes / 4 are published (owner lane and
+//     code, in LDS), and each lane runs ONE probe — with its shadow ray — of one of them, for
+//     whichever hit it belongs to;
+//   - the owners then read the outcomes of their quadrants and add the terms, mark the quadrant
+//     for filling, or set the four children in the next level's bit set;
+//   - the quadrants to fill are sampled by all lanes together, one quadrant (of 64 samples or more)
+//     or four (of 16) at a time.
+// This needs the random draws to be addressable: a draw is keyed by (hit, light, quadrant, number
+// within the quadrant), not by how many draws came before it (rt_math.h; the CPU checker follows
+// the same rule).  Each owner adds its terms in a fixed order (level, then code), so the result is
+// the same whichever lanes helped; the filled samples of a quadrant are summed in fixed point
+// (integer limbs) for the same reason.  Against the reference's depth-first f64 sum the order
+// differs, i.e. the result by rounding only.
 RT_DEV d3 phong_term(d3 n, d3 view, d3 diffuse, d3 specular, double shininess, double surface_dot, d3 light_direction, d3 intensity) {
     d3 reflection_direction = normalize(2.0 * surface_dot * n - light_direction);
     double specular_factor = shininess_pow(fmax(dot(reflection_direction, view), 0.0), shininess) / surface_dot;
@@ -182,131 +193,267 @@ RT_DEV d3 phong_term(d3 n, d3 view, d3 diffuse, d3 specular, double shininess, d
     return phong_color * surface_dot * intensity;
 }
 RT_DEV d3 bcast3(d3 v, int src) { return mk3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)); }
+RT_DEV uint64_t bcast_u64(uint64_t v, int src) { return ((uint64_t)__shfl((uint32_t)(v >> 32), src) << 32) | (uint64_t)__shfl((uint32_t)v, src); }
+// Sum of `v` over the lanes of `here` below this one, and over all of them (uniform control flow).
+RT_DEV void wave_exscan(unsigned long long here, uint32_t lane, uint32_t v, uint32_t& below, uint32_t& total) {
+    below = 0; total = 0;
+    for (unsigned long long m = here; m; m &= m - 1ull) {
+        const int l = __ffsll((long long)m) - 1;
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+        if ((uint32_t)l < lane) below += x;
+        total += x;
+    }
+}
+struct QuadBox { double minx, miny, maxx, maxy; };
+// The quadrant with position code `code` at `level` (0: the whole light), by the reference's own
+// arithmetic from the root down (light.rs:284-297; children in visiting order).
+RT_DEV QuadBox quad_box(double half, uint32_t level, uint32_t code) {
+    QuadBox b{-half, -half, half, half};
+    for (int k = (int)level - 1; k >= 0; --k) {
+        const uint32_t child = (code >> (2 * k)) & 3u;
+        const double hx = (b.maxx - b.minx) * 0.5, hy = (b.maxy - b.miny) * 0.5;
+        const double midx = b.minx + hx, midy = b.miny + hy;
+        if (child == 0u) { b.miny = b.miny + hy; b.maxx = b.maxx - hx; }          // (left, top)
+        else if (child == 1u) { b.minx = midx; b.miny = midy; }                    // (mid, max)
+        else if (child == 2u) { b.maxx = midx; b.maxy = midy; }                    // (min, mid)
+        else { b.minx = midx; b.maxy = b.maxy - hy; }                              // (bot, right)
+    }
+    return b;
+}
+RT_DEV uint32_t quad_node(uint32_t level, uint32_t code) { return ((1u << (2u * level)) - 1u) / 3u + code; }
+
+#define RT_AREA_WAVES(F) (((F) & RTF_LDS_BVH) ? 8 : 1)        // waves per workgroup of the kernels that shade area lights
+#define RT_AREA_LDS_BYTES(waves) ((waves) * 2048u)            // upper bound of the static LDS below, per workgroup
 template <uint32_t F, bool COUNT>
 RT_DEV void square_light(const DScene& sc, const DLight& L, PhongCtx& c, uint64_t stream, uint32_t path, Work<COUNT>& wk) {
-    __shared__ unsigned long long guess_acc[16][9];               // per wave: 3 channels x 3 limbs of weight 2^0, 2^-40, 2^-80
-    struct Quad { double minx, miny, maxx, maxy; uint32_t depth; };
-    Quad st[16];
-    int sp = 0;
-    double half = L.size * 0.5;
-    st[sp++] = Quad{-half, -half, half, half, 5u};                // SUB_DEPTH = 5, light.rs:187
-    uint32_t counter = 0;
+    constexpr int WAVES = RT_AREA_WAVES(F);
+    __shared__ uint16_t q_pub[WAVES][64];                          // this round's quadrants: owner lane << 8 | code
+    __shared__ __align__(4) uint8_t q_lit[WAVES][64];              // ... their probes' outcomes
+    __shared__ double q_term[WAVES][64][3];                        // ... and Phong terms (deepest level)
+    __shared__ uint16_t g_pub[WAVES][4];                           // the quadrants being filled
+    __shared__ unsigned long long g_acc[WAVES][4][9];              // ... 3 channels x 3 limbs of weight 2^0, 2^-40, 2^-80
+    const uint32_t lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) % WAVES;
+    const unsigned long long here = __ballot(1);
+    const uint32_t H = (uint32_t)__popcll(here), rank = (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
+    const uint32_t Q = H >= 4u ? H / 4u : 1u;                      // quadrants per round
+    const double half = L.size * 0.5;
     const d3 lpos = ld3(L.position), lcol = ld3(L.color);
-    const uint32_t lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) & 15u;
-    for (;;) {
-        const bool busy = sp > 0;
-        if (__ballot(busy) == 0ull) break;                         // idle lanes stay on as helpers
-        bool task = false;                                         // a batch of unshadowed samples to evaluate
-        double tminx = 0.0, tminy = 0.0, tmaxx = 0.0, tmaxy = 0.0, tap = 0.0;
-        uint32_t tn = 0, tcounter = 0;
-        if (busy) {
-            Quad q = st[--sp];
-            // subdivide_points :206-218 — four jittered samples, eight draws
-            double chx = q.maxx - q.minx, chy = q.maxy - q.miny;
-            double lowx = q.minx + chx * 0.25, lowy = q.miny + chy * 0.25;
-            double highx = q.minx + chx * 0.75, highy = q.miny + chy * 0.75;
-            double cx[4] = {lowx, highx, lowx, lowx + chx * 0.5};
-            double cz[4] = {lowy + chy * 0.5, highy, lowy, lowy};
-            double rx = chx * 0.25, ry = chy * 0.25;
-            double area_porp = (q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25;   // :251
-            double s_dot[4]; d3 s_dir[4]; d3 s_int[4]; bool s_lit[4];
-            uint32_t lit_count = 0;
-            for (int s = 0; s < 4; ++s) {
-                double dx = -rx + (rx - (-rx)) * rng_light(stream, path, L.index, counter++);
-                double dz = -ry + (ry - (-ry)) * rng_light(stream, path, L.index, counter++);
-                d3 light_pos = lpos + mk3(cx[s] + dx, 0.0, cz[s] + dz);
-                d3 hit_to_light = light_pos - c.p;
-                d3 light_direction = normalize(hit_to_light);
-                double surface_dot = dot(light_direction, c.n);
-                s_lit[s] = false;
-                if (surface_dot <= 0.0) continue;
-                double light_distance = length(hit_to_light);
-                if (occluded<F, COUNT>(sc, c.p, light_direction, light_distance, wk)) continue;
-                s_lit[s] = true; s_dot[s] = surface_dot; s_dir[s] = light_direction;
-                s_int[s] = lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
-                lit_count++;
+    const d3 lcp = lcol * L.power;
+    uint32_t cur[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, nxt[8];
+    for (uint32_t level = 0; level < 5u; ++level) {                // SUB_DEPTH = 5, light.rs:187
+        const uint32_t depth = 5u - level;
+        uint32_t cnt = 0;
+        for (int w = 0; w < 8; ++w) cnt += (uint32_t)__popc(cur[w]);
+        uint32_t lo, total;
+        wave_exscan(here, lane, cnt, lo, total);
+        if (total == 0u) break;
+        for (int w = 0; w < 8; ++w) nxt[w] = 0u;
+        unsigned long long fill = 0ull;                            // quadrants of this level to fill with samples (levels 0..3: codes < 64)
+        uint32_t taken = 0, cw = 0, cm = cur[0];
+        for (uint32_t base = 0; base < total; base += Q) {
+            // ---- owners publish their quadrants number base .. base+Q-1 of the wave
+            uint32_t my_first = 0, my_n = 0;
+            while (taken < cnt && lo + taken < base + Q) {
+                while (cm == 0u) cm = cur[++cw];
+                const uint32_t code = cw * 32u + (uint32_t)(__ffs((int)cm) - 1);
+                cm &= cm - 1u;
+                const uint32_t slot = lo + taken - base;
+                if (my_n == 0u) my_first = slot;
+                q_pub[wave][slot] = (uint16_t)((lane << 8) | code);
+                ++my_n; ++taken;
             }
-            if (q.depth == 1 || lit_count == 0) {                 // :277-279
-                for (int s = 0; s < 4; ++s) if (s_lit[s]) { RT_COUNT(wk, shade_evals); phong_lit(c, s_dot[s], s_dir[s], s_int[s]); }
-            } else if (lit_count == 4) {                          // guess_illums :222-245
-                task = true;
-                tminx = q.minx; tminy = q.miny; tmaxx = q.maxx; tmaxy = q.maxy;
-                tn = 1u << (2 * q.depth);
-                tap = 4.0 * area_porp / (double)tn;
-                tcounter = counter;
-                counter += 2u * tn;
-            } else {                                              // :284-297, children pushed in reverse visiting order
-                double hx = (q.maxx - q.minx) * 0.5, hy = (q.maxy - q.miny) * 0.5;
-                double midx = q.minx + hx, midy = q.miny + hy;
-                if (sp + 4 <= 16) {
-                    st[sp++] = Quad{q.minx + hx, q.miny, q.maxx, q.maxy - hy, q.depth - 1};   // (bot, right)
-                    st[sp++] = Quad{q.minx, q.miny, midx, midy, q.depth - 1};                 // (min, mid)
-                    st[sp++] = Quad{midx, midy, q.maxx, q.maxy, q.depth - 1};                 // (mid, max)
-                    st[sp++] = Quad{q.minx, q.miny + hy, q.maxx - hx, q.maxy, q.depth - 1};   // (left, top)
-                }
-            }
-        }
-        unsigned long long pend = __ballot(task);
-        if (pend == 0ull) continue;
-        const unsigned long long here = __ballot(1);
-        const uint32_t helpers = (uint32_t)__popcll(here), rank = (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
-        while (pend) {
-            const int src = __ffsll((long long)pend) - 1;
-            pend &= pend - 1ull;
-            // the owner's hit and batch
-            const d3 P = bcast3(c.p, src), N = bcast3(c.n, src), V = bcast3(c.view, src);
-            const d3 KD = bcast3(c.diffuse, src), KS = bcast3(c.specular, src);
-            const double SH = __shfl(c.shininess, src);
-            const double bminx = __shfl(tminx, src), bminy = __shfl(tminy, src), bmaxx = __shfl(tmaxx, src), bmaxy = __shfl(tmaxy, src);
-            const double bap = __shfl(tap, src);
-            const uint32_t bn = __shfl(tn, src), bcounter = __shfl(tcounter, src), bpath = __shfl(path, src);
-            const uint64_t bstream = ((uint64_t)__shfl((uint32_t)(stream >> 32), src) << 32) | (uint64_t)__shfl((uint32_t)stream, src);
-            if ((int)lane == src) for (int k = 0; k < 9; ++k) guess_acc[wave][k] = 0ull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            double l[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            bool odd = false;                                      // a term that fixed point cannot hold (non-finite, huge)
-            for (uint32_t i = rank; i < bn; i += helpers) {
-                double sx = bminx + (bmaxx - bminx) * rng_light(bstream, bpath, L.index, bcounter + 2u * i);
-                double sz = bminy + (bmaxy - bminy) * rng_light(bstream, bpath, L.index, bcounter + 2u * i + 1u);
-                d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - P;
-                double light_distance = length(hit_to_light);
-                d3 light_direction = hit_to_light / light_distance;
-                double surface_dot = dot(light_direction, N);
-                RT_COUNT(wk, shade_evals);
-                d3 term = phong_term(N, V, KD, KS, SH, surface_dot, light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * bap);
-                const double tv[3] = {term.x, term.y, term.z};
-                for (int ch = 0; ch < 3; ++ch) {
-                    const double v = tv[ch];
-                    if (!(fabs(v) < 0x1p40)) { odd = true; continue; }
-                    double l0 = trunc(v);
-                    double r1 = (v - l0) * 0x1p40;
-                    double l1 = trunc(r1);
-                    double l2 = trunc((r1 - l1) * 0x1p40);
-                    l[3 * ch] += l0; l[3 * ch + 1] += l1; l[3 * ch + 2] += l2;
-                }
-            }
-            for (int k = 0; k < 9; ++k) if (l[k] != 0.0) atomicAdd(&guess_acc[wave][k], (unsigned long long)(long long)l[k]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool any_odd = __ballot(odd) != 0ull;
-            if ((int)lane == src) {
-                if (any_odd) {                                    // rare: evaluate this batch the reference's way, term by term
-                    for (uint32_t i = 0; i < tn; ++i) {
-                        double sx = tminx + (tmaxx - tminx) * rng_light(stream, path, L.index, tcounter + 2u * i);
-                        double sz = tminy + (tmaxy - tminy) * rng_light(stream, path, L.index, tcounter + 2u * i + 1u);
-                        d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - c.p;
-                        double light_distance = length(hit_to_light);
-                        d3 light_direction = hit_to_light / light_distance;
-                        phong_lit(c, dot(light_direction, c.n), light_direction, lcol * L.power / (4.0 * RT_PI * light_distance * light_distance) * tap);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- one probe per lane (several in turn when fewer than four lanes are here)
+            const uint32_t nq = min(Q, total - base);
+            for (uint32_t t = 0; t * H < 4u * nq; ++t) {
+                const uint32_t item = t * H + rank;
+                const bool valid = item < 4u * nq;
+                const uint32_t s = item & 3u;
+                const uint32_t e = q_pub[wave][valid ? item >> 2 : 0u];
+                const int owner = valid ? (int)(e >> 8) : (int)lane;
+                const uint32_t code = e & 255u;
+                const d3 P = bcast3(c.p, owner), N = bcast3(c.n, owner);
+                const uint64_t ostream = bcast_u64(stream, owner);
+                const uint32_t opath = __shfl(path, owner);
+                d3 V = mk3(0.0, 0.0, 0.0), KD = V, KS = V;
+                double SH = 1.0;
+                if (depth == 1u) { V = bcast3(c.view, owner); KD = bcast3(c.diffuse, owner); KS = bcast3(c.specular, owner); SH = __shfl(c.shininess, owner); }
+                bool lit = false;
+                if (valid) {
+                    // subdivide_points :206-218 — this probe's jittered point
+                    const QuadBox q = quad_box(half, level, code);
+                    const double chx = q.maxx - q.minx, chy = q.maxy - q.miny;
+                    const double lowx = q.minx + chx * 0.25, lowy = q.miny + chy * 0.25;
+                    const double highx = q.minx + chx * 0.75, highy = q.miny + chy * 0.75;
+                    const double cx = s == 1u ? highx : (s == 3u ? lowx + chx * 0.5 : lowx);
+                    const double cz = s == 0u ? lowy + chy * 0.5 : (s == 1u ? highy : lowy);
+                    const double rx = chx * 0.25, ry = chy * 0.25;
+                    const double area_porp = (q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25;   // :251
+                    const uint32_t draw = quad_node(level, code) * 2048u + 2u * s;
+                    const double dx = -rx + (rx - (-rx)) * rng_light(ostream, opath, L.index, draw);
+                    const double dz = -ry + (ry - (-ry)) * rng_light(ostream, opath, L.index, draw + 1u);
+                    const d3 hit_to_light = (lpos + mk3(cx + dx, 0.0, cz + dz)) - P;
+                    const d3 light_direction = normalize(hit_to_light);
+                    const double surface_dot = dot(light_direction, N);
+                    if (surface_dot > 0.0) {
+                        const double light_distance = length(hit_to_light);
+                        if (!occluded<F, COUNT>(sc, P, light_direction, light_distance, wk)) {
+                            lit = true;
+                            if (depth == 1u) {                     // :277-279: the deepest level's probes are the samples
+                                const d3 intensity = lcp / (4.0 * RT_PI * light_distance * light_distance) * area_porp;   // :365-368, :270
+                                st3(q_term[wave][item], phong_term(N, V, KD, KS, SH, surface_dot, light_direction, intensity));
+                            }
+                        }
                     }
-                } else {
-                    const unsigned long long* g = guess_acc[wave];
-                    c.total = c.total + mk3(((double)(long long)g[2] * 0x1p-80 + (double)(long long)g[1] * 0x1p-40) + (double)(long long)g[0],
-                                            ((double)(long long)g[5] * 0x1p-80 + (double)(long long)g[4] * 0x1p-40) + (double)(long long)g[3],
-                                            ((double)(long long)g[8] * 0x1p-80 + (double)(long long)g[7] * 0x1p-40) + (double)(long long)g[6]);
+                    q_lit[wave][item] = lit ? 1 : 0;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- owners read the outcomes of their quadrants, in order
+            for (uint32_t j = 0; j < my_n; ++j) {
+                const uint32_t slot = my_first + j;
+                const uint32_t code = q_pub[wave][slot] & 255u;
+                const uint32_t lit4 = *reinterpret_cast<const uint32_t*>(&q_lit[wave][4u * slot]) & 0x01010101u;
+                if (depth == 1u) {
+                    for (uint32_t s = 0; s < 4u; ++s)
+                        if ((lit4 >> (8u * s)) & 1u) { RT_COUNT(wk, shade_evals); c.total = c.total + ld3(q_term[wave][4u * slot + s]); }
+                } else if (lit4 == 0x01010101u) {
+                    fill |= 1ull << code;
+                } else if (lit4 != 0u) {
+                    nxt[(4u * code) >> 5] |= 0xFu << ((4u * code) & 31u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        // ---- fill the quadrants whose four probes were lit: 4^depth samples each, no shadow tests
+        uint32_t fcnt = (uint32_t)__popcll(fill), flo, ftotal;
+        wave_exscan(here, lane, fcnt, flo, ftotal);
+        if (ftotal != 0u) {
+            const uint32_t tn = 1u << (2u * depth);
+            const uint32_t G = (tn == 16u && H == 64u) ? 4u : 1u;   // small quadrants: four at a time, sixteen lanes each
+            const uint32_t per = H / G;
+            // Whole-number exponents (the usual case) are raised by squaring under scalar control flow when
+            // one quadrant is filled at a time: every lane then has the same exponent.
+            uint32_t ftaken = 0;
+            for (uint32_t fbase = 0; fbase < ftotal; fbase += G) {
+                    uint32_t my_first = 0, my_n = 0;
+                while (ftaken < fcnt && flo + ftaken < fbase + G) {
+                    const uint32_t code = (uint32_t)(__ffsll((long long)fill) - 1);
+                    fill &= fill - 1ull;
+                    const uint32_t slot = flo + ftaken - fbase;
+                    if (my_n == 0u) my_first = slot;
+                    g_pub[wave][slot] = (uint16_t)((lane << 8) | code);
+                    for (int k = 0; k < 9; ++k) g_acc[wave][slot][k] = 0ull;
+                    ++my_n; ++ftaken;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t g = rank / per, r = rank % per;
+                const bool valid = fbase + g < ftotal;
+                const uint32_t e = g_pub[wave][valid ? g : 0u];
+                const int owner = valid ? (int)(e >> 8) : (int)lane;
+                const uint32_t code = e & 255u;
+                const d3 P = bcast3(c.p, owner), N = bcast3(c.n, owner), V = bcast3(c.view, owner);
+                const d3 KD = bcast3(c.diffuse, owner), KS = bcast3(c.specular, owner);
+                const double SH = __shfl(c.shininess, owner);
+                const uint64_t ostream = bcast_u64(stream, owner);
+                const uint32_t opath = __shfl(path, owner);
+                const QuadBox q = quad_box(half, level, code);
+                const double bap = 4.0 * ((q.maxx - q.minx) * (q.maxy - q.miny) * L.inv_area * 0.25) / (double)tn;   // :223-224
+                const uint32_t draw0 = quad_node(level, code) * 2048u + 8u;
+                const double wx = q.maxx - q.minx, wz = q.maxy - q.miny;
+                const bool whole = SH >= 1.0 && SH <= 64.0 && SH == floor(SH);
+                const bool uniform_expo = G == 1u && __builtin_amdgcn_readfirstlane((int)whole) != 0;
+                const uint32_t expo = uniform_expo ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)SH) : 0u;
+                double l[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                bool odd = false;                                  // a term that the fast arithmetic or fixed point cannot hold
+                for (uint32_t i = r; i < (valid ? tn : 0u); i += per) {
+                    double u, v;
+                    rng_light_pair(ostream, opath, L.index, draw0 + i, u, v);
+                    const double sx = q.minx + wx * u, sz = q.miny + wz * v;
+                    const d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - P;
+                    // The divisions and square roots below are the IEEE ones, computed without the range
+                    // scaling of the general sequences and with one reciprocal per divisor; `odd` sends a
+                    // quadrant with a divisor outside their range to the term-by-term evaluation.
+                    const double d2 = dot(hit_to_light, hit_to_light);
+                    const double light_distance = sqrt_nr(d2);
+                    const double rcp_distance = rcp_nr(light_distance);
+                    const d3 light_direction = mk3(div_nr(hit_to_light.x, light_distance, rcp_distance),
+                                                   div_nr(hit_to_light.y, light_distance, rcp_distance),
+                                                   div_nr(hit_to_light.z, light_distance, rcp_distance));
+                    const double surface_dot = dot(light_direction, N);
+                    RT_COUNT(wk, shade_evals);
+                    const double spread = 4.0 * RT_PI * light_distance * light_distance;       // get_intensity :365-368
+                    const double rcp_spread = rcp_nr(spread);
+                    const d3 intensity = mk3(div_nr(lcp.x, spread, rcp_spread), div_nr(lcp.y, spread, rcp_spread), div_nr(lcp.z, spread, rcp_spread)) * bap;
+                    // phong_term(N, V, KD, KS, SH, surface_dot, light_direction, intensity)
+                    const d3 rv = 2.0 * surface_dot * N - light_direction;
+                    const double r2 = dot(rv, rv);
+                    const double rlen = sqrt_nr(r2);
+                    const d3 reflection_direction = rv * div_nr(1.0, rlen, rcp_nr(rlen));
+                    double x = fmax(dot(reflection_direction, V), 0.0), powered;
+                    if (uniform_expo) {
+                        powered = 1.0;
+                        for (uint32_t ex = expo; ex; ex >>= 1) { if (ex & 1u) powered *= x; x *= x; }
+                    } else {
+                        powered = shininess_pow(x, SH);
+                    }
+                    const double specular_factor = div_nr(powered, surface_dot, rcp_nr(surface_dot));
+                    const d3 phong_color = KS * specular_factor + KD;
+                    const d3 term = phong_color * surface_dot * intensity;
+                    odd |= !((int)nr_in_range(d2) & (int)nr_in_range(r2) & (int)nr_in_range(surface_dot));
+                    odd |= !(fabs(term.x) < 0x1p40) | !(fabs(term.y) < 0x1p40) | !(fabs(term.z) < 0x1p40);
+                    const double tv[3] = {term.x, term.y, term.z};
+                    for (int ch = 0; ch < 3; ++ch) {               // limbs of an odd term are never used
+                        const double l0 = trunc(tv[ch]);
+                        const double r1 = (tv[ch] - l0) * 0x1p40;
+                        const double l1 = trunc(r1);
+                        const double l2 = trunc((r1 - l1) * 0x1p40);
+                        l[3 * ch] += l0; l[3 * ch + 1] += l1; l[3 * ch + 2] += l2;
+                    }
+                }
+                const unsigned long long odd_lanes = __ballot(odd);
+                const unsigned long long group_lanes = G == 1u ? ~0ull : 0xFFFFull << (16u * g);   // (G == 4 only when all 64 lanes are here: rank == lane)
+                if (valid && (odd_lanes & group_lanes) == 0ull)
+                    for (int k = 0; k < 9; ++k) if (l[k] != 0.0) atomicAdd(&g_acc[wave][g][k], (unsigned long long)(long long)l[k]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = 0; j < my_n; ++j) {
+                    const uint32_t slot = my_first + j;
+                    const bool slot_odd = (odd_lanes & (G == 1u ? ~0ull : 0xFFFFull << (16u * slot))) != 0ull;
+                    if (slot_odd) {                                // rare: this quadrant the reference's way, term by term
+                        const uint32_t mcode = g_pub[wave][slot] & 255u;
+                        const QuadBox mq = quad_box(half, level, mcode);
+                        const double tap = 4.0 * ((mq.maxx - mq.minx) * (mq.maxy - mq.miny) * L.inv_area * 0.25) / (double)tn;
+                        const uint32_t mdraw = quad_node(level, mcode) * 2048u + 8u;
+                        for (uint32_t i = 0; i < tn; ++i) {
+                            double u, v;
+                            rng_light_pair(stream, path, L.index, mdraw + i, u, v);
+                            const double sx = mq.minx + (mq.maxx - mq.minx) * u;
+                            const double sz = mq.miny + (mq.maxy - mq.miny) * v;
+                            const d3 hit_to_light = (lpos + mk3(sx, 0.0, sz)) - c.p;
+                            const double light_distance = length(hit_to_light);
+                            const d3 light_direction = hit_to_light / light_distance;
+                            phong_lit(c, dot(light_direction, c.n), light_direction, lcp / (4.0 * RT_PI * light_distance * light_distance) * tap);
+                        }
+                    } else {
+                        const unsigned long long* a = g_acc[wave][slot];
+                        c.total = c.total + mk3(((double)(long long)a[2] * 0x1p-80 + (double)(long long)a[1] * 0x1p-40) + (double)(long long)a[0],
+                                                ((double)(long long)a[5] * 0x1p-80 + (double)(long long)a[4] * 0x1p-40) + (double)(long long)a[3],
+                                                ((double)(long long)a[8] * 0x1p-80 + (double)(long long)a[7] * 0x1p-40) + (double)(long long)a[6]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        for (int w = 0; w < 8; ++w) cur[w] = nxt[w];
     }
 }
 
