@@ -147,14 +147,18 @@ struct TraceArgs {
     uint32_t* acc_flags;
 };
 
-template <uint32_t F, bool COUNT>
+// HOT: the scene's small tables (instances, primitives, shaders, lights ...) are copied into the
+// workgroup's LDS first and read from there; only for variants without meshes, whose LDS is free.
+template <uint32_t F, bool COUNT, bool HOT = false>
 // At least two waves per SIMD, i.e. at most 256 registers: left alone the area-light variants take 448
 // and run one wave per SIMD, which was measured 15 % (light_room) to 40 % (monkey_1) slower; three
 // waves per SIMD spill too much and are slower again.
 __global__ void __launch_bounds__((F & RTF_LDS_BVH) ? 512 : 64) __attribute__((amdgpu_waves_per_eu(2)))
-k_trace(DScene sc, DRenderParams rp, TraceArgs a) {
+k_trace(DScene gsc, DRenderParams rp, TraceArgs a) {
+    static_assert(!HOT || !(F & RTF_MESH), "the mesh variants keep their walk stacks and BVH in LDS");
     const uint32_t queued = a.round > 0 ? min(*a.in_count, a.queue_cap) : 0u;
     if (a.round > 0 && queued == 0) return;                         // nothing was handed on: uniform exit
+    const DScene sc = localise_scene<HOT>(gsc, rt_lds_dynamic);
     if constexpr (F & RTF_LDS_BVH) {
         // stage every mesh's BVH nodes and triangles into LDS once per workgroup
         const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);

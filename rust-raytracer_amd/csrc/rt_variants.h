@@ -39,6 +39,7 @@ RT_WF_VARIANTS(RT_DECLARE_WF)
 #undef RT_DECLARE_WF
 LaunchStatus rt_launch_wf_walk(bool count, uint32_t num_cus, hipStream_t stream, const DScene& ds, const WfArgs& wa);   // num_cus: the chain's share of the CUs
 
+#define RT_TRACE_HOT_LIMIT (12u * 1024u)   // largest table copy per 64-thread workgroup of the persistent kernel (eight of them share a CU's LDS)
 // ---- bodies, instantiated by the variant files only
 template <uint32_t F>
 LaunchStatus launch_trace_variant(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta) {
@@ -49,6 +50,17 @@ LaunchStatus launch_trace_variant(bool count, uint32_t grid, hipStream_t stream,
         auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return {ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"};
+    }
+    // Scenes whose lights are sampled inside the shader and that have no meshes: every shadow test reads the
+    // instance and primitive tables, one dependent read after another; out of LDS (eight 64-thread
+    // workgroups per CU, a copy each) the wait is a fraction of what it is out of L2.
+    if constexpr ((F & RTF_INLINE_LIGHTS) && !(F & RTF_MESH)) {
+        if (ds.hot_bytes > 0 && ds.hot_bytes <= RT_TRACE_HOT_LIMIT) {
+            const uint32_t tables = (ds.hot_bytes + 15u) & ~15u;
+            if (count) hipLaunchKernelGGL((k_trace<F, true, true>), dim3(grid), dim3(block), tables, stream, ds, rp, ta);
+            else hipLaunchKernelGGL((k_trace<F, false, true>), dim3(grid), dim3(block), tables, stream, ds, rp, ta);
+            return {hipGetLastError(), "k_trace launch"};
+        }
     }
     if (count) hipLaunchKernelGGL((k_trace<F, true>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
     else hipLaunchKernelGGL((k_trace<F, false>), dim3(grid), dim3(block), lds, stream, ds, rp, ta);
