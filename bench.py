@@ -221,17 +221,19 @@ def main():
         for k in stage_ms:
             stage_ms[k] /= args.steps
         # dominant launch sequence of rank 0's share
+        launches = ("k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation" if full.get("schedule") == 1
+                    else "k_trace, persistent lanes")
         if stage_ms["aa"] >= stage_ms["pass1"]:
-            kernel, k_ms, k_flops = "AA-resolve pass (k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation)", stage_ms["aa"], flops_aa
+            which, kernel, k_ms, k_flops = "aa", f"AA-resolve pass ({launches})", stage_ms["aa"], flops_aa
         else:
-            kernel, k_ms, k_flops = "pass 1 (k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation)", stage_ms["pass1"], flops_pass1
+            which, kernel, k_ms, k_flops = "pass1", f"pass 1 ({launches})", stage_ms["pass1"], flops_pass1
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         fb_bytes = width * height * (32 + 3)   # f64 colour+distance written once, RGB8 written once
         traffic, traffic_rec = measured_traffic(args.config, world)
         roofline = {"bound": "valu_fp64", "kernel": kernel, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                     "peak_no_fma": FP64_VECTOR_PEAK_NO_FMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "frac_no_fma": achieved / FP64_VECTOR_PEAK_NO_FMA_TFLOPS,
-                    "traffic": traffic,
+                    "traffic": (traffic_rec or {}).get("bytes_" + which), "traffic_per_frame": traffic,
                     "algorithmic_flops_per_launch": int(k_flops), "avg_launch_ms": k_ms,
                     "hbm_secondary": {"algorithmic_bytes_per_frame": fb_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "achieved_algorithmic": fb_bytes / (ms_per_step * 1e-3) / 1e9}}

@@ -203,7 +203,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
         hot.insert(hot.end(), p, p + bytes);
     };
 #define HOT(field, vec) pack(vec.data(), vec.size() * sizeof(vec[0]), reinterpret_cast<const void**>(&d.field))
-    HOT(instances, fs.instances); HOT(mesh_instances, fs.mesh_instances); HOT(prims, fs.prims); HOT(tris, fs.tris); HOT(polys, fs.polys);
+    HOT(instances, fs.instances); HOT(inst_box, fs.inst_box); HOT(mesh_instances, fs.mesh_instances); HOT(prims, fs.prims); HOT(tris, fs.tris); HOT(polys, fs.polys);
     HOT(points, fs.points); HOT(faced, fs.faced); HOT(meshes, fs.meshes); HOT(csg_roots, fs.csg_roots); HOT(csg_ops, fs.csg_ops);
     HOT(csg_leaves, fs.csg_leaves); HOT(shaders, fs.shaders); HOT(shader_bounds, fs.shader_bounds); HOT(shader_child_idx, fs.shader_child_idx);
     HOT(shader_child_weight, fs.shader_child_weight); HOT(chain_nmaps, fs.chain_nmaps); HOT(normal_maps, fs.normal_maps);
@@ -221,6 +221,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     d.num_instances = (uint32_t)fs.instances.size();
     d.num_mesh_instances = (uint32_t)fs.mesh_instances.size();
     d.num_unbounded = (uint32_t)fs.tlas_unbounded.size();
+    d.inst_box_mask = fs.inst_box_mask;
     d.num_lights = (uint32_t)fs.lights.size();
     std::memcpy(d.ambient, fs.ambient, sizeof d.ambient);
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;

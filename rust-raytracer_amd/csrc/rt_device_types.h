@@ -193,6 +193,8 @@ struct DScene {
     const uint32_t* tlas_index;      // leaf contents: instance indices
     const uint32_t* tlas_unbounded;  // instances without a finite box (planes, polyhedra, composites): always tested
     uint32_t num_unbounded;
+    const double* inst_box;          // scenes without a TLAS: per instance its world-space box, lo[3] hi[3]; null when no instance is worth a box test
+    uint32_t inst_box_mask;          // ... bit i: test instance i's box before the instance itself
     const DPrim* prims;
     const DTri* tris;
     const DPoly* polys;

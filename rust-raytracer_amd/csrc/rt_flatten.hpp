@@ -113,6 +113,8 @@ struct FlatScene {
     std::vector<uint32_t> mesh_instances;
     std::vector<DBvhNode> tlas_nodes;
     std::vector<uint32_t> tlas_index, tlas_unbounded;
+    std::vector<double> inst_box;   // without a TLAS: world-space lo, hi of every instance (infinite where it has no finite box)
+    uint32_t inst_box_mask = 0;     // ... and which of the first 32 instances are worth the box test
     std::vector<DPrim> prims;
     std::vector<DTri> tris;
     std::vector<DPoly> polys;
@@ -450,6 +452,7 @@ private:
             if (p.kind == DP_MESH && !p.wrap) fs_.mesh_instances.push_back(i);
         }
         build_tlas();
+        build_instance_boxes((f & RTF_INLINE_LIGHTS) != 0);
         if (!fs_.tlas_nodes.empty()) f |= RTF_TLAS;
         fs_.shader_bounds.assign(d_.num_shaders, 0u);
         for (uint32_t i = 0; i < d_.num_shaders; ++i) {
@@ -485,27 +488,58 @@ private:
             default: return false;   // Plane, Polygon, Polyhedron, composite shapes
         }
     }
+    // World-space box of instance i, padded generously (the hit distance is measured in instance space and
+    // scaled back, not in world space); false when its primitive has no finite box.
+    bool instance_world_box(uint32_t i, V3& blo, V3& bhi) const {
+        const DInstance& in = fs_.instances[i];
+        V3 lo, hi;
+        if (!prim_bounds(fs_.prims[in.prim], lo, hi)) return false;
+        const double inf = std::numeric_limits<double>::infinity();
+        V3 wlo{inf, inf, inf}, whi{-inf, -inf, -inf};
+        const double* m = in.x.l2w.r;
+        for (int c = 0; c < 8; ++c) {
+            V3 q{c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z};
+            V3 w{m[0] * q.x + m[1] * q.y + m[2] * q.z + m[3], m[4] * q.x + m[5] * q.y + m[6] * q.z + m[7], m[8] * q.x + m[9] * q.y + m[10] * q.z + m[11]};
+            wlo = {std::min(wlo.x, w.x), std::min(wlo.y, w.y), std::min(wlo.z, w.z)};
+            whi = {std::max(whi.x, w.x), std::max(whi.y, w.y), std::max(whi.z, w.z)};
+        }
+        V3 ext = whi - wlo;
+        double pad = 1e-6 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-9 * (std::fabs(wlo.x) + std::fabs(wlo.y) + std::fabs(wlo.z) + std::fabs(whi.x) + std::fabs(whi.y) + std::fabs(whi.z)) + 1e-12;
+        blo = wlo - V3{pad, pad, pad}; bhi = whi + V3{pad, pad, pad};
+        return true;
+    }
+    // Scenes too small for a TLAS: the flat loop over the instances skips those whose box the ray misses, where
+    // that saves more than the test costs.  In the persistent kernel (scenes whose lights are sampled inside the
+    // shader: `every_kind`) an instance costs two dependent table reads before any arithmetic, and its shadow
+    // tests end at the light, before the walls: every bounded instance gets the test (measured: light_room
+    // 35.5 -> 32 ms).  In the queue pipeline's analytic kernel, which is bound by its arithmetic, a rectangle in a
+    // uniformly scaled frame is tested almost as cheaply as its box (the test made glass_monkey's walls 2 %
+    // slower): only spheres, cubes, tetrahedra, triangles and anything under a non-uniform scale (whose ray
+    // direction has to be normalised again) get it.
+    void build_instance_boxes(bool every_kind) {
+        fs_.inst_box.clear();
+        fs_.inst_box_mask = 0;
+        if (!fs_.tlas_nodes.empty()) return;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (uint32_t i = 0; i < fs_.instances.size(); ++i) {
+            const DInstance& in = fs_.instances[i];
+            const uint32_t kind = fs_.prims[in.prim].kind;
+            const bool costly = every_kind || kind == DP_SPHERE || kind == DP_FACED || kind == DP_TRIANGLE || (in.x.uniform_s == 0.0 && kind != DP_MESH);
+            V3 lo, hi;
+            if (costly && i < 32 && instance_world_box(i, lo, hi)) fs_.inst_box_mask |= 1u << i;
+            else { lo = {-inf, -inf, -inf}; hi = {inf, inf, inf}; }
+            for (double v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) fs_.inst_box.push_back(v);
+        }
+        if (!fs_.inst_box_mask) fs_.inst_box.clear();
+    }
     void build_tlas() {
         if (fs_.instances.size() < RT_TLAS_MIN_INSTANCES) return;
         std::vector<BuildTri> bt;
         for (uint32_t i = 0; i < fs_.instances.size(); ++i) {
-            const DInstance& in = fs_.instances[i];
-            V3 lo, hi;
-            if (!prim_bounds(fs_.prims[in.prim], lo, hi)) { fs_.tlas_unbounded.push_back(i); continue; }
-            const double inf = std::numeric_limits<double>::infinity();
-            V3 wlo{inf, inf, inf}, whi{-inf, -inf, -inf};
-            const double* m = in.x.l2w.r;
-            for (int c = 0; c < 8; ++c) {
-                V3 q{c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z};
-                V3 w{m[0] * q.x + m[1] * q.y + m[2] * q.z + m[3], m[4] * q.x + m[5] * q.y + m[6] * q.z + m[7], m[8] * q.x + m[9] * q.y + m[10] * q.z + m[11]};
-                wlo = {std::min(wlo.x, w.x), std::min(wlo.y, w.y), std::min(wlo.z, w.z)};
-                whi = {std::max(whi.x, w.x), std::max(whi.y, w.y), std::max(whi.z, w.z)};
-            }
-            // generous padding: the hit distance is measured in instance space and scaled back, not in world space
-            V3 ext = whi - wlo;
-            double pad = 1e-6 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-9 * (std::fabs(wlo.x) + std::fabs(wlo.y) + std::fabs(wlo.z) + std::fabs(whi.x) + std::fabs(whi.y) + std::fabs(whi.z)) + 1e-12;
+            V3 plo, phi;
+            if (!instance_world_box(i, plo, phi)) { fs_.tlas_unbounded.push_back(i); continue; }
             BuildTri b;
-            b.lo = wlo - V3{pad, pad, pad}; b.hi = whi + V3{pad, pad, pad}; b.c = (b.lo + b.hi) * 0.5; b.face = i;
+            b.lo = plo; b.hi = phi; b.c = (b.lo + b.hi) * 0.5; b.face = i;
             bt.push_back(b);
         }
         if (bt.size() < RT_TLAS_MIN_INSTANCES) { fs_.tlas_unbounded.clear(); return; }

@@ -43,7 +43,7 @@ RT_DEV DScene localise_scene(const DScene& sc, uint8_t* lds) {
     for (uint32_t i = threadIdx.x; i < sc.hot_bytes / 16u; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 #define RT_REBASE(field) if (sc.field) l.field = reinterpret_cast<decltype(l.field)>(lds + (reinterpret_cast<const uint8_t*>(sc.field) - sc.hot_blob))
-    RT_REBASE(instances); RT_REBASE(mesh_instances); RT_REBASE(prims); RT_REBASE(tris); RT_REBASE(polys); RT_REBASE(points);
+    RT_REBASE(instances); RT_REBASE(inst_box); RT_REBASE(mesh_instances); RT_REBASE(prims); RT_REBASE(tris); RT_REBASE(polys); RT_REBASE(points);
     RT_REBASE(faced); RT_REBASE(meshes); RT_REBASE(csg_roots); RT_REBASE(csg_ops); RT_REBASE(csg_leaves);
     RT_REBASE(shaders); RT_REBASE(shader_bounds); RT_REBASE(shader_child_idx); RT_REBASE(shader_child_weight);
     RT_REBASE(chain_nmaps); RT_REBASE(normal_maps); RT_REBASE(images); RT_REBASE(gamma_lut); RT_REBASE(lights);
@@ -1064,8 +1064,25 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
             }
         }
     }
-    if (!walked)
-        for (uint32_t i = 0; i < sc.num_instances; ++i) if (visit(i)) return true;
+    if (!walked) {
+        // Few instances, no TLAS: where the host found it worth while (inst_box_mask), an instance's world-space
+        // box is tested first.  Changing into a sphere's or a cube's space and testing it costs several times
+        // the box test, and most rays miss most boxes (a shadow test ends before it reaches far objects; after
+        // the first hit only nearer boxes matter).
+        if (sc.inst_box_mask) {
+            const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            for (uint32_t i = 0; i < sc.num_instances; ++i) {
+                if (i < 32u && ((sc.inst_box_mask >> i) & 1u)) {
+                    double tn;
+                    RT_COUNT(wk, box_tests);
+                    if (!slab(sc.inst_box + 6u * i, sc.inst_box + 6u * i + 3u, o, inv, best, tn)) continue;
+                }
+                if (visit(i)) return true;
+            }
+        } else {
+            for (uint32_t i = 0; i < sc.num_instances; ++i) if (visit(i)) return true;
+        }
+    }
     hit.t = best;
     return found;
 }
