@@ -43,13 +43,13 @@ def small_view(scene, width, **kw):
 
 @pytest.fixture(scope="module")
 def device_scene(render_mod, scene_cache):
-    cache = {}   # the most recently used few: every device scene owns gigabytes of ray queues
+    cache = {}   # the most recently used sixteen (a device scene owns its ray queues: 8 entries per pixel of the largest frame it has rendered, at least 2^20)
 
     def get(name):
         if name in cache:
             cache[name] = cache.pop(name)
         else:
-            while len(cache) >= 4:
+            while len(cache) >= 16:
                 cache.pop(next(iter(cache))).close()
             cache[name] = render_mod.DeviceScene(scene_cache(name), device=0)
         return cache[name]
