@@ -1010,9 +1010,20 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
         if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) return false; }
+        RT_COUNT(wk, instance_tests);
+        if (p.kind == DP_RECTANGLE && !((F & RTF_WRAP) && p.wrap)) {
+            // A rectangle lies in its frame's z = 0 plane, and the ray meets that plane at -o.z / d.z (rect_hit): the
+            // two z components alone (the same expressions to_local evaluates, a seventh of its work) settle most
+            // rectangles of a room.  Same sign: the plane lies behind the ray, rect_hit would return false.  Beyond
+            // the best distance so far (any-hit: beyond the light) by more than any rounding of the quotient: the
+            // hit would lose the comparison that follows.
+            const double* mt = in.x.w2l.r;
+            const double oz = ((mt[8] * o.x + mt[9] * o.y) + mt[10] * o.z) + mt[11];
+            const double vz = (mt[8] * d.x + mt[9] * d.y) + mt[10] * d.z;
+            if (oz * vz > 0.0 || fabs(oz) > (best * fabs(vz)) * (1.0 + 1e-9)) return false;
+        }
         double s, inv_s;
         LRay lr = to_local(in.x, o, d, s, inv_s);
-        RT_COUNT(wk, instance_tests);
         Cand c;
         bool got;
         bool direct_mesh = false;

@@ -299,10 +299,13 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         } else {
             const uint32_t flags = a.rays.U(cap, RQ_FLAGS, q);
             o = a.rays.ld3(cap, RQ_O, q); d = a.rays.ld3(cap, RQ_D, q);
-            const d3 rc = a.rays.ld3(cap, RQ_C, q);
             // gate of Scene::cast_ray (scene.rs:67): terminated rays still see the background
-            // (a listed query has passed it already)
-            if (!REDO && !(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
+            // (a listed query has passed it already; without a sky box a ray that fails the gate is never queued,
+            // QueueSink::ray, and camera rays pass it whenever recursion_depth > 0: its 28 bytes stay unread)
+            const bool gated = !REDO && (sc.has_background != 0 || rp.recursion_depth == 0);
+            d3 rc = mk3(1.0, 1.0, 1.0);
+            if (gated) rc = a.rays.ld3(cap, RQ_C, q);
+            if (gated && !(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
                 const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
                 // its colour term: the background (k_wf_accumulate adds it); exactly nothing without a sky box
                 if (sc.has_background) {
