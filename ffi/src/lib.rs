@@ -260,6 +260,14 @@ pub struct RtAux {
     pub ms_encode: f64,
 }
 
+/// Stages reported to an `RtProgressFn` (src/progress_tracker.rs:37-42).
+pub const RT_PROGRESS_START: u32 = 0;
+pub const RT_PROGRESS_PASS1: u32 = 1;
+pub const RT_PROGRESS_START_AA: u32 = 2;
+pub const RT_PROGRESS_AA: u32 = 3;
+pub const RT_PROGRESS_END: u32 = 4;
+pub type RtProgressFn = Option<unsafe extern "C" fn(user: *mut c_void, stage: u32, done: u64, total: u64, elapsed_seconds: f64)>;
+
 /// Opaque: the flattened scene, resident in device memory.
 pub enum RtScene {}
 
@@ -277,6 +285,10 @@ extern "C" {
                                     cfg: *const RtRenderConfig, d_rgb_out: *mut u8, hip_stream: *mut c_void) -> c_int;
     pub fn rt_owned_rows_capacity(height: u32, nranks: u32, tile_rows: u32) -> u32;
     pub fn rt_last_timings(scene: *const RtScene, ms_pass1: *mut f64, ms_aa: *mut f64, ms_encode: *mut f64) -> c_int;
+    pub fn rt_write_png(device: c_int, rgb: *const u8, width: u32, height: u32, file_name: *const c_char) -> c_int;
+    pub fn rt_write_png_device(device: c_int, d_rgb: *const u8, width: u32, height: u32, file_name: *const c_char,
+                               hip_stream: *mut c_void) -> c_int;
+    pub fn rt_set_progress(scene: *mut RtScene, callback: RtProgressFn, user: *mut c_void) -> c_int;
 }
 
 /// The message of the last failing call on this thread.

@@ -317,6 +317,33 @@ uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_
  * rt_render_device call on `scene`, per stage; blocks until that call finished. */
 int rt_last_timings(const RtScene* scene, double* ms_pass1, double* ms_aa, double* ms_encode);
 
+/* ---- output stage: the step after the path ---- */
+
+/* write_to_png (src/lib.rs:41-46): the frame as "<file_name>.png" (the reference appends the
+ * extension the same way and creates no directories).  `rgb` is host memory in the layout rt_render
+ * leaves (W*H*3, top row first).  The scanline filters are chosen and applied on `device` (one
+ * workgroup per row), the host deflates and writes the file.  Any PNG decoder returns exactly the
+ * bytes of `rgb`.  The reference prints "save successful" / "FAILED TO SAVE" and returns nothing;
+ * this returns a status instead and prints nothing. */
+int rt_write_png(int device, const uint8_t* rgb, uint32_t width, uint32_t height, const char* file_name);
+
+/* The same for a frame still in device memory (what rt_render_device leaves in d_rgb_out with
+ * nranks <= 1); blocks until the file is written. */
+int rt_write_png_device(int device, const uint8_t* d_rgb, uint32_t width, uint32_t height,
+                        const char* file_name, void* hip_stream);
+
+/* ProgressTracker (src/progress_tracker.rs:37-42,48-77).  A frame runs on the device without
+ * coming back to the host, so rt_render reports its stages once the frame is complete, in the
+ * tracker's order and with the device's clock: RT_PROGRESS_START (done 0, total = pixels:
+ * "START RENDERING"), RT_PROGRESS_PASS1 (done = total = pixels traced by pass 1, elapsed = its
+ * device time), RT_PROGRESS_START_AA (done 0, total = pixels the detector flagged: "START
+ * ANTIALIASING: n / total"), RT_PROGRESS_AA (done = total = flagged pixels), RT_PROGRESS_END
+ * (elapsed = device time of the whole frame: "Elapsed Time").  `fn` = NULL switches reporting off.
+ * Called on the thread that called rt_render, before it returns. */
+enum { RT_PROGRESS_START = 0, RT_PROGRESS_PASS1 = 1, RT_PROGRESS_START_AA = 2, RT_PROGRESS_AA = 3, RT_PROGRESS_END = 4 };
+typedef void (*RtProgressFn)(void* user, uint32_t stage, uint64_t done, uint64_t total, double elapsed_seconds);
+int rt_set_progress(RtScene* scene, RtProgressFn fn, void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ def _run(cmd):
 
 
 def build_hip(force=False, jobs=None):
-    """csrc/rt_api.hip and every csrc/variants/*.hip compile to objects side by side (csrc/obj/), then link."""
+    """every csrc/*.hip and csrc/variants/*.hip compile to objects side by side (csrc/obj/), then link."""
     from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(HERE, "csrc")
     obj_dir = os.path.join(src_dir, "obj")
@@ -42,7 +42,8 @@ def build_hip(force=False, jobs=None):
     headers = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".h", ".hpp"))]
     headers.append(os.path.join(INCLUDE, "rt_amd.h"))
     var_dir = os.path.join(src_dir, "variants")
-    sources = [os.path.join(src_dir, "rt_api.hip")] + sorted(os.path.join(var_dir, f) for f in os.listdir(var_dir) if f.endswith(".hip"))
+    sources = sorted(os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith(".hip")) + \
+        sorted(os.path.join(var_dir, f) for f in os.listdir(var_dir) if f.endswith(".hip"))
     flags = [f for f in HIP_FLAGS if f != "-shared"]
     todo, objects = [], []
     for src in sources:
@@ -55,7 +56,7 @@ def build_hip(force=False, jobs=None):
         with ThreadPoolExecutor(max_workers=jobs) as pool:
             list(pool.map(_run, todo))
     if todo or _newer(HIP_LIB, objects):
-        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objects])
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objects, "-lz"])   # zlib: the PNG writer's deflate
     return HIP_LIB
 
 

@@ -91,6 +91,9 @@ int upload(const std::vector<T>& v, std::vector<void*>& owned, const T** out) {
 
 }  // namespace
 
+// The other translation units of the library report their errors through the same thread-local message.
+int rt_set_error(int code, const std::string& msg) { return fail(code, msg); }
+
 // Device memory one frame works in.  A scene owns one (grown on demand with hipMalloc, reused from
 // frame to frame); the entry point that allocates nothing builds a temporary one over the static scratch array.
 struct Workspace {
@@ -136,6 +139,8 @@ struct RtScene {
     // queue pipeline as several chains side by side: chain 0 runs on the caller's stream, the others on these
     hipStream_t chain_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t chain_fork = nullptr, chain_join[3] = {nullptr, nullptr, nullptr};
+    RtProgressFn progress = nullptr;       // rt_set_progress
+    void* progress_user = nullptr;
 };
 
 extern "C" {
@@ -882,10 +887,31 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             std::fprintf(stderr, "\n");
         }
     }
-    if (aux) {
-        double a = 0, b = 0, c = 0;
-        if (rt_last_timings(scene, &a, &b, &c) == RT_OK) { aux->ms_pass1 = a; aux->ms_aa = b; aux->ms_encode = c; }
+    double ms_a = 0, ms_b = 0, ms_c = 0;
+    const bool have_ms = rt_last_timings(scene, &ms_a, &ms_b, &ms_c) == RT_OK;
+    if (aux && have_ms) { aux->ms_pass1 = ms_a; aux->ms_aa = ms_b; aux->ms_encode = ms_c; }
+    if (s->progress) {   // the stages of src/progress_tracker.rs:59-73, after the fact
+        unsigned int flagged = 0;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (cfg->anti_alias) HIP_TRY(hipMemcpy(&flagged, static_cast<char*>(s->ws.scalars.p) + SC_AA_COUNT * 4, sizeof flagged, hipMemcpyDeviceToHost));
+        }
+        const uint64_t traced = (uint64_t)rt_owned_rows_capacity(dim->height, cfg->nranks, cfg->tile_rows) * dim->width;
+        s->progress(s->progress_user, RT_PROGRESS_START, 0, npix, 0.0);
+        s->progress(s->progress_user, RT_PROGRESS_PASS1, std::min<uint64_t>(traced, npix), npix, ms_a * 1e-3);
+        if (cfg->anti_alias) {
+            s->progress(s->progress_user, RT_PROGRESS_START_AA, 0, flagged, ms_a * 1e-3);
+            s->progress(s->progress_user, RT_PROGRESS_AA, flagged, flagged, (ms_a + ms_b) * 1e-3);
+        }
+        s->progress(s->progress_user, RT_PROGRESS_END, npix, npix, (ms_a + ms_b + ms_c) * 1e-3);
     }
+    return RT_OK;
+}
+
+int rt_set_progress(RtScene* scene, RtProgressFn fn, void* user) {
+    if (!scene) return fail(RT_ERR_INVALID_ARG, "rt_set_progress: null scene");
+    std::lock_guard<std::mutex> lk(scene->mu);
+    scene->progress = fn; scene->progress_user = user;
     return RT_OK;
 }
 

@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")   # RT_AMD_LIB: another build of the same library (kernel tuning experiments)
 
 EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
-           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status", "rt_render_device_noalloc"]
+           "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status", "rt_render_device_noalloc",
+           "rt_write_png", "rt_write_png_device", "rt_set_progress"]
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double)
 
 _lib = None
 
@@ -51,8 +54,27 @@ def hip_lib():
                                                  C.c_void_p, C.c_void_p]
         lib.rt_frame_status.restype = C.c_int
         lib.rt_frame_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.rt_write_png.restype = C.c_int
+        lib.rt_write_png.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]
+        lib.rt_write_png_device.restype = C.c_int
+        lib.rt_write_png_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p]
+        lib.rt_set_progress.restype = C.c_int
+        lib.rt_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p]
         _lib = lib
     return _lib
+
+
+def write_png(rgb, file_name, device=0):
+    """rt_write_png: an (H, W, 3) uint8 array as "<file_name>.png" (src/lib.rs:41-46)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    _check(hip_lib().rt_write_png(device, rgb.ctypes.data, w, h, os.fsencode(file_name)))
+
+
+def write_png_device(d_rgb_ptr, width, height, file_name, device=0, stream_ptr=None):
+    """rt_write_png_device: the same for a frame in device memory."""
+    _check(hip_lib().rt_write_png_device(device, C.c_void_p(d_rgb_ptr), width, height, os.fsencode(file_name),
+                                         C.c_void_p(stream_ptr) if stream_ptr else None))
 
 
 def _check(rc):
@@ -109,6 +131,11 @@ class DeviceScene:
         """rt_render_device_noalloc: like render_device, workspace in the library's static device array."""
         _check(hip_lib().rt_render_device_noalloc(self._handle, C.byref(dim), C.byref(cam), C.byref(cfg), C.c_void_p(d_rgb_ptr),
                                                   C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_progress(self, fn):
+        """rt_set_progress: fn(stage, done, total, elapsed_seconds) after every rt_render frame (None: off)."""
+        self._progress = PROGRESS_FN(lambda user, stage, done, total, t: fn(stage, done, total, t)) if fn else PROGRESS_FN()
+        _check(hip_lib().rt_set_progress(self._handle, self._progress, None))
 
     def last_timings(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
