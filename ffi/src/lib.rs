@@ -260,6 +260,25 @@ pub struct RtAux {
     pub ms_encode: f64,
 }
 
+/// Where `rt_scene_create_with` prepares a scene (hierarchies of the meshes, image flip).
+pub const RT_INGEST_AUTO: u32 = 0;
+pub const RT_INGEST_HOST: u32 = 1;
+pub const RT_INGEST_DEVICE: u32 = 2;
+pub const RT_INGEST_AUTO_FACES: u32 = 65536;
+
+/// `Mesh::from_path` (src/mesh.rs:383-414) on the device: the arrays are the library's until `rt_obj_release`.
+#[repr(C)]
+pub struct RtObjMesh {
+    pub num_positions: u32,
+    pub num_normals: u32,
+    pub num_texcoords: u32,
+    pub num_faces: u32,
+    pub positions: *mut f64,
+    pub normals: *mut f64,
+    pub texcoords: *mut f64,
+    pub faces: *mut u32,
+}
+
 /// Stages reported to an `RtProgressFn` (src/progress_tracker.rs:37-42).
 pub const RT_PROGRESS_START: u32 = 0;
 pub const RT_PROGRESS_PASS1: u32 = 1;
@@ -285,6 +304,9 @@ extern "C" {
                                     cfg: *const RtRenderConfig, d_rgb_out: *mut u8, hip_stream: *mut c_void) -> c_int;
     pub fn rt_owned_rows_capacity(height: u32, nranks: u32, tile_rows: u32) -> u32;
     pub fn rt_last_timings(scene: *const RtScene, ms_pass1: *mut f64, ms_aa: *mut f64, ms_encode: *mut f64) -> c_int;
+    pub fn rt_scene_create_with(desc: *const RtSceneDesc, device: c_int, ingest: u32, out: *mut *mut RtScene) -> c_int;
+    pub fn rt_obj_parse(device: c_int, text: *const c_char, bytes: u64, out: *mut RtObjMesh) -> c_int;
+    pub fn rt_obj_release(mesh: *mut RtObjMesh);
     pub fn rt_write_png(device: c_int, rgb: *const u8, width: u32, height: u32, file_name: *const c_char) -> c_int;
     pub fn rt_write_png_device(device: c_int, d_rgb: *const u8, width: u32, height: u32, file_name: *const c_char,
                                hip_stream: *mut c_void) -> c_int;

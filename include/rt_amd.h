@@ -317,6 +317,36 @@ uint32_t rt_owned_rows_capacity(uint32_t height, uint32_t nranks, uint32_t tile_
  * rt_render_device call on `scene`, per stage; blocks until that call finished. */
 int rt_last_timings(const RtScene* scene, double* ms_pass1, double* ms_aa, double* ms_encode);
 
+/* ---- scene ingest: the step before the path ---- */
+
+/* rt_scene_create with a say in where the scene is prepared.  The reference prepares a mesh on the
+ * host when it is loaded (the bounding tree of src/mesh.rs:124-144,281-332) and flips every image
+ * after decoding it (src/texture.rs:46, src/normal_map.rs:52,116).  RT_INGEST_HOST does both on the
+ * host, RT_INGEST_DEVICE on `device` (one launch per level of a hierarchy, one workgroup per node;
+ * the rows of an image change places where they landed), RT_INGEST_AUTO (what rt_scene_create
+ * uses) on the device from RT_INGEST_AUTO_FACES mesh faces / 1 MiB of texels on.  Both give the
+ * same device scene, bit for bit. */
+enum { RT_INGEST_AUTO = 0, RT_INGEST_HOST = 1, RT_INGEST_DEVICE = 2 };
+#define RT_INGEST_AUTO_FACES 65536u
+int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, RtScene** out);
+
+/* Mesh::from_path (src/mesh.rs:383-414) without the file: Wavefront OBJ text -> the unified-vertex
+ * triangle mesh that tobj 0.1.7's load_obj hands the reference (every distinct v/vt/vn corner of a
+ * model — an `o` / `g` block with faces — one vertex, in order of first appearance; polygons as
+ * triangle fans; positions, normals and texture coordinates parsed as f32 and widened), parsed on
+ * `device`.  The arrays are host memory owned by the library until rt_obj_release; they are what
+ * RtMesh / mesh_f64 / mesh_u32 of an RtSceneDesc take.  Texture coordinates and normals exist only
+ * for vertices whose corner names one, like the reference's arrays. */
+typedef struct RtObjMesh {
+    uint32_t num_positions, num_normals, num_texcoords, num_faces;
+    double* positions;     /* 3 per vertex */
+    double* normals;       /* 3 per normal */
+    double* texcoords;     /* 2 per texture coordinate */
+    uint32_t* faces;       /* 3 per face */
+} RtObjMesh;
+int rt_obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out);
+void rt_obj_release(RtObjMesh* mesh);
+
 /* ---- output stage: the step after the path ---- */
 
 /* write_to_png (src/lib.rs:41-46): the frame as "<file_name>.png" (the reference appends the

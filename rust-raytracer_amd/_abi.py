@@ -115,6 +115,12 @@ class RtMesh(C.Structure):
                 ("positions_off", C.c_uint64), ("normals_off", C.c_uint64), ("texcoords_off", C.c_uint64), ("faces_off", C.c_uint64)]
 
 
+class RtObjMesh(C.Structure):
+    _fields_ = [("num_positions", C.c_uint32), ("num_normals", C.c_uint32), ("num_texcoords", C.c_uint32), ("num_faces", C.c_uint32),
+                ("positions", C.POINTER(C.c_double)), ("normals", C.POINTER(C.c_double)), ("texcoords", C.POINTER(C.c_double)),
+                ("faces", C.POINTER(C.c_uint32))]
+
+
 class RtSceneDesc(C.Structure):
     """Read-only view used by tests to inspect a description produced by the host layer."""
     _fields_ = [

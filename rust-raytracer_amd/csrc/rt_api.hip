@@ -94,6 +94,10 @@ int upload(const std::vector<T>& v, std::vector<void*>& owned, const T** out) {
 // The other translation units of the library report their errors through the same thread-local message.
 int rt_set_error(int code, const std::string& msg) { return fail(code, msg); }
 
+// rt_ingest.hip: the meshes' hierarchies built on `device`, and images flipped where they land
+rtflat::MeshBuilder rt_device_mesh_builder(int device);
+hipError_t rt_device_flip_rows(uint8_t* texels, uint32_t row_bytes, uint32_t height, hipStream_t stream);
+
 // Device memory one frame works in.  A scene owns one (grown on demand with hipMalloc, reused from
 // frame to frame); the entry point that allocates nothing builds a temporary one over the static scratch array.
 struct Workspace {
@@ -173,13 +177,23 @@ void rt_scene_destroy(RtScene* s) {
     delete s;
 }
 
-int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
+int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) { return rt_scene_create_with(desc, device, RT_INGEST_AUTO, out); }
+
+int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, RtScene** out) {
     if (!desc || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
     *out = nullptr;
+    if (ingest > RT_INGEST_DEVICE) return fail(RT_ERR_INVALID_ARG, "rt_scene_create_with: unknown ingest mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARG, "device index out of range");
     rtflat::FlatScene fs;
+    {   // where the meshes' hierarchies are built and the images flipped: both give the same scene, bit for bit
+        uint64_t faces = 0;
+        for (uint32_t i = 0; desc->meshes && i < desc->num_meshes; ++i) faces += desc->meshes[i].num_faces;
+        const bool on_device = ingest == RT_INGEST_DEVICE || (ingest == RT_INGEST_AUTO && faces >= RT_INGEST_AUTO_FACES);
+        if (on_device) fs.mesh_builder = rt_device_mesh_builder(device);
+        fs.flip_on_device = ingest == RT_INGEST_DEVICE || (ingest == RT_INGEST_AUTO && desc->texel_bytes >= (1u << 20));
+    }
     try {
         rtflat::flatten(*desc, fs);
     } catch (const rtflat::Unsupported& e) {
@@ -223,6 +237,11 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(texels, fs.texels);
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+    if (fs.flip_on_device)
+        for (const DImage& im : fs.images) {
+            hipError_t fe = rt_device_flip_rows(const_cast<uint8_t*>(d.texels) + im.offset, im.width * im.channels, im.height, nullptr);
+            if (fe != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, std::string("image flip: ") + hipGetErrorString(fe)); }
+        }
     d.num_instances = (uint32_t)fs.instances.size();
     d.num_mesh_instances = (uint32_t)fs.mesh_instances.size();
     d.num_unbounded = (uint32_t)fs.tlas_unbounded.size();

@@ -108,6 +108,15 @@ inline V3 normalize(V3 a) { return a * (1.0 / length(a)); }
 inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 
 // ---- the flattened scene (host copies; uploaded verbatim) ----
+// What a bounding-hierarchy build works on and produces: per triangle its box, the box's centre and the face it
+// came from (in the order the leaves hold them); per node its box, its children (or -1) and its range of triangles.
+struct BuildTri { V3 lo, hi, c; uint32_t face; };
+struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+// A mesh build that runs somewhere else (on the device, rt_ingest.hip): same inputs and outputs as the host's
+// build_bvh below, and the same tree, node for node.
+using MeshBuilder = std::function<void(const double* positions, uint32_t num_positions, const uint32_t* faces, uint32_t num_faces,
+                                       int max_depth, std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes)>;
+
 struct FlatScene {
     std::vector<DInstance> instances;
     std::vector<uint32_t> mesh_instances;
@@ -142,13 +151,13 @@ struct FlatScene {
     DAffine background_w2l{};
     uint32_t max_mesh_bvh_bytes = 0;
     uint32_t features = 0, max_ray_spawn = 0, max_shadow_spawn = 0, inline_point_lights = 0;
+    MeshBuilder mesh_builder;        // empty: the host builds the meshes' hierarchies
+    bool flip_on_device = false;     // images are staged top row first and flipped once they are in device memory
     std::vector<uint8_t> lds_blob;   // LBvhNode + LMeshTri arrays of all meshes
     bool lds_exact = true;           // every mesh coordinate is an f32 value, so the f32 vertex copies lose nothing
 };
 
 // ---- BVH build: binned SAH, leaves of <= 2 triangles (measured: 4 costs 2 % more, 1 costs 18 % more on the north-star scene) ----
-struct BuildTri { V3 lo, hi, c; uint32_t face; };
-struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
 // `max_depth`: the walk that will use the tree keeps one stack entry per level, so a tree may not grow
 // deeper than that stack; a subtree that reaches the limit becomes a leaf if its count still fits the
@@ -208,7 +217,7 @@ inline void build_bvh(std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes
     } else {
         double a0 = best_axis == 0 ? clo.x : best_axis == 1 ? clo.y : clo.z, a1 = best_axis == 0 ? chi.x : best_axis == 1 ? chi.y : chi.z;
         double k = BINS / (a1 - a0);
-        auto it = std::partition(tris.begin() + first, tris.begin() + first + count, [&](const BuildTri& t) {
+        auto it = std::stable_partition(tris.begin() + first, tris.begin() + first + count, [&](const BuildTri& t) {
             double c = best_axis == 0 ? t.c.x : best_axis == 1 ? t.c.y : t.c.z;
             return std::min(BINS - 1, (int)((c - a0) * k)) <= best_bin;
         });
@@ -229,16 +238,21 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     const uint32_t* F = d.mesh_u32 + m.faces_off;
     auto pos = [&](uint32_t i) { if (i >= m.num_positions) throw Invalid("mesh face index out of range"); return V3{P[3 * i], P[3 * i + 1], P[3 * i + 2]}; };
     std::vector<BuildTri> bt(m.num_faces);
-    for (uint32_t f = 0; f < m.num_faces; ++f) {
-        V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
-        bt[f].lo = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
-        bt[f].hi = {std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z))};
-        bt[f].c = (bt[f].lo + bt[f].hi) * 0.5;
-        bt[f].face = f;
-    }
     std::vector<BuildNode> bn(1);
-    bn.reserve(2 * m.num_faces + 2);
-    build_bvh(bt, bn, 0, 0, m.num_faces, 0, RT_BVH_STACK - 2);
+    if (fs.mesh_builder) {
+        for (uint32_t f = 0; f < 3 * m.num_faces; ++f) if (F[f] >= m.num_positions) throw Invalid("mesh face index out of range");
+        fs.mesh_builder(P, m.num_positions, F, m.num_faces, RT_BVH_STACK - 2, bt, bn);
+    } else {
+        for (uint32_t f = 0; f < m.num_faces; ++f) {
+            V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
+            bt[f].lo = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
+            bt[f].hi = {std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z))};
+            bt[f].c = (bt[f].lo + bt[f].hi) * 0.5;
+            bt[f].face = f;
+        }
+        bn.reserve(2 * m.num_faces + 2);
+        build_bvh(bt, bn, 0, 0, m.num_faces, 0, RT_BVH_STACK - 2);
+    }
     // pad boxes so that slab-test rounding can never cull a triangle lying on a box face
     V3 ext = bn[0].hi - bn[0].lo;
     double pad = 1e-9 * std::max(ext.x, std::max(ext.y, ext.z)) + 1e-300;
@@ -760,8 +774,11 @@ private:
             while (fs_.texels.size() % 16) fs_.texels.push_back(0);
             o.offset = fs_.texels.size();
             fs_.texels.resize(o.offset + row * s.height);
-            for (uint32_t y = 0; y < s.height; ++y)   // flip_vertical: texture.rs:46, normal_map.rs:52,116
-                std::memcpy(&fs_.texels[o.offset + (size_t)y * row], d_.texels + s.offset + (size_t)(s.height - 1 - y) * row, row);
+            if (fs_.flip_on_device)                   // rows as decoded; the caller flips them after the upload
+                std::memcpy(&fs_.texels[o.offset], d_.texels + s.offset, row * s.height);
+            else
+                for (uint32_t y = 0; y < s.height; ++y)   // flip_vertical: texture.rs:46, normal_map.rs:52,116
+                    std::memcpy(&fs_.texels[o.offset + (size_t)y * row], d_.texels + s.offset + (size_t)(s.height - 1 - y) * row, row);
             fs_.images.push_back(o);
         }
         for (uint32_t i = 0; i < d_.num_normal_maps; ++i) {

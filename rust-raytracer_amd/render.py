@@ -7,14 +7,16 @@ import os
 
 import numpy as np
 
-from ._abi import RT_OK, RtAux, RtCamera, RtImageDim, RtRenderConfig
+from ._abi import RT_OK, RtAux, RtCamera, RtImageDim, RtObjMesh, RtRenderConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "librt_amd.so")   # RT_AMD_LIB: another build of the same library (kernel tuning experiments)
 
 EXPORTS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render",
            "rt_render_device", "rt_owned_rows_capacity", "rt_last_timings", "rt_frame_status", "rt_render_device_noalloc",
-           "rt_write_png", "rt_write_png_device", "rt_set_progress"]
+           "rt_write_png", "rt_write_png_device", "rt_set_progress", "rt_scene_create_with", "rt_obj_parse", "rt_obj_release"]
+
+INGEST_AUTO, INGEST_HOST, INGEST_DEVICE = 0, 1, 2
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double)
 
@@ -54,6 +56,11 @@ def hip_lib():
                                                  C.c_void_p, C.c_void_p]
         lib.rt_frame_status.restype = C.c_int
         lib.rt_frame_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.rt_scene_create_with.restype = C.c_int
+        lib.rt_scene_create_with.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rt_obj_parse.restype = C.c_int
+        lib.rt_obj_parse.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.POINTER(RtObjMesh)]
+        lib.rt_obj_release.argtypes = [C.POINTER(RtObjMesh)]
         lib.rt_write_png.restype = C.c_int
         lib.rt_write_png.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]
         lib.rt_write_png_device.restype = C.c_int
@@ -62,6 +69,22 @@ def hip_lib():
         lib.rt_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p]
         _lib = lib
     return _lib
+
+
+def obj_parse(text, device=0):
+    """rt_obj_parse: OBJ text (bytes) -> dict of numpy arrays (positions (n,3), normals (n,3), texcoords (n,2), faces (n,3))."""
+    lib = hip_lib()
+    m = RtObjMesh()
+    _check(lib.rt_obj_parse(device, text, len(text), C.byref(m)))
+    try:
+        def take(ptr, rows, cols, dtype):
+            if rows == 0:
+                return np.zeros((0, cols), dtype=dtype)
+            return np.ctypeslib.as_array(ptr, shape=(rows, cols)).astype(dtype, copy=True)
+        return {"positions": take(m.positions, m.num_positions, 3, np.float64), "normals": take(m.normals, m.num_normals, 3, np.float64),
+                "texcoords": take(m.texcoords, m.num_texcoords, 2, np.float64), "faces": take(m.faces, m.num_faces, 3, np.uint32)}
+    finally:
+        lib.rt_obj_release(C.byref(m))
 
 
 def write_png(rgb, file_name, device=0):
@@ -85,12 +108,15 @@ def _check(rc):
 class DeviceScene:
     """A scene flattened and resident in HBM (rt_scene_create)."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, ingest=None):
         lib = hip_lib()
         self.scene = scene   # keeps the description alive
         self.device = device
         handle = C.c_void_p()
-        _check(lib.rt_scene_create(scene.desc, device, C.byref(handle)))
+        if ingest is None:
+            _check(lib.rt_scene_create(scene.desc, device, C.byref(handle)))
+        else:   # rt_scene_create_with: where the hierarchies are built and the images flipped (INGEST_*)
+            _check(lib.rt_scene_create_with(scene.desc, device, ingest, C.byref(handle)))
         self._handle = handle
 
     @property

@@ -32,7 +32,7 @@ def test_no_device_here_is_reported_not_faked(render_mod):
 
 def test_struct_layouts_match_the_header(abi_mod):
     names = ["RtImageDim", "RtCamera", "RtRenderConfig", "RtCounters", "RtAux", "RtNode", "RtPrim", "RtCsgNode",
-             "RtShader", "RtLight", "RtImage", "RtNormalMap", "RtMesh", "RtSceneDesc"]
+             "RtShader", "RtLight", "RtImage", "RtNormalMap", "RtMesh", "RtSceneDesc", "RtObjMesh"]
     src = '#include <stdio.h>\n#include "rt_amd.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
