@@ -563,6 +563,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     };
     // ---- the other schedule: ray queues in HBM, one generation of rays per set of launches
     WfArgs wa{};
+    uint32_t gen0_tiles = 0;               // generation 0 dealt out in tiles: bit 0 pass 1, bit 1 AA resolve
     if (wavefront) {
         const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
         for (auto& b : w.wf_rays) if ((e = b.ensure(n * (RQ_NF * 8 + RQ_NU * 4))) != RT_OK) return e;
@@ -587,12 +588,22 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         wa.dropped = (unsigned int*)s->wf_sticky.p;
         wa.rows = (const uint32_t*)w.rows.p; wa.num_rows = num_rows; wa.aa_count = aa_count;
         { const char* dbg = std::getenv("RT_WF_DEBUG"); wa.debug = dbg ? (uint32_t)std::atoi(dbg) : 0u; }
+        {   // Generation 0 in tiles of 8 x 8 pixels (coherent waves) for scenes whose queries walk a hierarchy over the
+            // instances in the analytic kernel, one lane each: there neighbouring rays save most (many_balls_forest 4K);
+            // elsewhere ray-by-ray dealing keeps the sub-queues more even (glass_monkey: tiles cost 3 %).  RT_WF_TILES overrides.
+            uint32_t tiles = s->ds.tlas_nodes != nullptr ? 3u : 0u;                        // bit 0: pass 1, bit 1: AA resolve
+            if (const char* te = std::getenv("RT_WF_TILES")) tiles = (uint32_t)std::atoi(te) & 3u;
+            const uint64_t tile_runs = (uint64_t)((W + 7u) / 8u) * ((num_rows + 7u) / 8u);
+            if (((tile_runs + RT_WF_Q - 1u) / RT_WF_Q) * 64u > wa.sub) tiles &= ~1u;      // the padded frame must fit generation 0's sub-queues
+            gen0_tiles = tiles;
+        }
     }
     auto run_wavefront = [&](uint32_t mode, double* dst) -> int {
         unsigned int* ws = (unsigned int*)w.wf_scalars.p + mode * WF_PASS_WORDS;
         const uint32_t generations = std::min(rc.recursion_depth + 1, WF_MAX_GEN);
         const uint32_t grid = std::max(1u, (uint32_t)s->num_cus * 16 / RT_WF_Q) * RT_WF_Q;   // a whole number of workgroups per sub-queue
         wa.mode = mode;
+        wa.gen0_tiles = (gen0_tiles >> mode) & 1u;
         wa.list = (const uint32_t*)w.list.p;
         // generation 0 into queue set 0
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };

@@ -119,6 +119,7 @@ struct WfArgs {
     const uint32_t* list;
     const unsigned int* aa_count;
     uint32_t mode;
+    uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
     uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
 };
 
@@ -194,26 +195,16 @@ RT_DEV void wf_flush(DCounters* g, const Work<COUNT>& wk, unsigned long long cam
 __global__ void __launch_bounds__(256)
 k_wf_generate(DRenderParams rp, WfArgs a) {
     const uint32_t W = rp.cam.width;
+    const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
+    const d3 cam_o = ld3(rp.cam.origin);
     // (pass 1: the host has checked that the frame's pixels fit the queues.  AA resolve: the number of
     // flagged pixels is only known on the device; samples that do not fit are counted as lost, which
     // makes the host redo the frame with larger queues)
     const unsigned long long aa_want = a.mode == 0 ? 0ull : (unsigned long long)*a.aa_count * rp.aa_rays;
-    const uint32_t total = a.mode == 0 ? W * a.num_rows : (uint32_t)min(aa_want, (unsigned long long)a.cap);
-    if (a.mode != 0 && aa_want > a.cap && blockIdx.x == 0 && threadIdx.x == 0)
-        atomicAdd(a.dropped, (unsigned int)min(aa_want - a.cap, 0x7FFFFFFFull));
-    // item i goes to sub-queue i % RT_WF_Q
-    if (blockIdx.x == 0) {
-        for (uint32_t sq = threadIdx.x; sq < RT_WF_Q; sq += blockDim.x) {
-            a.n_out[2 * sq] = total / RT_WF_Q + (sq < total % RT_WF_Q ? 1u : 0u); a.n_out[2 * sq + 1] = 0;
-        }
-    }
-    const double theta = 2.0 * RT_PI / (double)rp.aa_rays;        // render.rs:227
-    const d3 cam_o = ld3(rp.cam.origin);
-    // thread t writes entry t % per of sub-queue t / per: neighbouring lanes fill neighbouring entries
-    const uint32_t per = (total + RT_WF_Q - 1u) / RT_WF_Q;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < per * RT_WF_Q; t += gridDim.x * blockDim.x) {
-        const uint32_t item = (t % per) * RT_WF_Q + t / per;
-        if (item >= total) continue;
+    const unsigned long long aa_room = a.gen0_tiles ? (unsigned long long)RT_WF_Q * (a.sub / 64u) * 64ull : (unsigned long long)a.cap;   // (whole runs of 64 per sub-queue)
+    if (a.mode != 0 && aa_want > aa_room && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(a.dropped, (unsigned int)min(aa_want - aa_room, 0x7FFFFFFFull));
+    auto emit = [&](uint32_t e, uint32_t item) {
         d3 dir;
         uint32_t slot;
         if (a.mode == 0) {
@@ -232,12 +223,59 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
             dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
             slot = item;
         }
-        const uint32_t e = (item % RT_WF_Q) * a.sub + item / RT_WF_Q;
         const WfQueue& r = a.out_rays;
         r.st3(a.cap, RQ_O, e, cam_o); r.st3(a.cap, RQ_D, e, dir);
         r.st3(a.cap, RQ_W, e, mk3(1.0, 1.0, 1.0)); r.st3(a.cap, RQ_C, e, mk3(1.0, 1.0, 1.0));
         r.U(a.cap, RQ_DEPTH, e) = rp.recursion_depth; r.U(a.cap, RQ_PATH, e) = 1u;
         r.U(a.cap, RQ_SLOT, e) = slot; r.U(a.cap, RQ_FLAGS, e) = a.mode == 0 ? 3u : 2u;
+    };
+    if (a.gen0_tiles) {
+        // Coherent dealing: a wave's worth of neighbouring camera rays stays together.  Pass 1: the frame's rows
+        // (in the order of `rows`) are cut into tiles of 8 x 8 pixels, tile t goes to sub-queue t % RT_WF_Q as 64
+        // consecutive entries; pixels of a tile beyond the frame's edge become holes (flag 8).  AA resolve: runs
+        // of 64 consecutive samples (neighbouring flagged pixels) are dealt out the same way.  Rays that start
+        // together take the same way through a scene's bounding hierarchy, and so do the shadow tests and rays
+        // their hits spawn, which sit side by side in the next generation.
+        const uint32_t tw = (W + 7u) / 8u;
+        const unsigned long long slots = a.mode == 0 ? (unsigned long long)tw * ((a.num_rows + 7u) / 8u) * 64ull : min(aa_want, aa_room);
+        const uint32_t chunks = (uint32_t)((slots + 63ull) / 64ull);
+        if (blockIdx.x == 0) {
+            for (uint32_t sq = threadIdx.x; sq < RT_WF_Q; sq += blockDim.x) {
+                uint32_t n = (chunks / RT_WF_Q + (sq < chunks % RT_WF_Q ? 1u : 0u)) * 64u;
+                if (chunks && sq == (chunks - 1u) % RT_WF_Q) n -= (uint32_t)((unsigned long long)chunks * 64ull - slots);   // the last run may be short
+                a.n_out[2 * sq] = n; a.n_out[2 * sq + 1] = 0;
+            }
+        }
+        const uint32_t per = ((chunks + RT_WF_Q - 1u) / RT_WF_Q) * 64u;
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < per * RT_WF_Q; t += gridDim.x * blockDim.x) {
+            const uint32_t entry = t % per, sq = t / per;
+            const uint32_t chunk = (entry / 64u) * RT_WF_Q + sq;
+            const unsigned long long u = (unsigned long long)chunk * 64ull + entry % 64u;
+            if (chunk >= chunks || u >= slots) continue;
+            const uint32_t e = sq * a.sub + entry;
+            if (a.mode == 0) {
+                const uint32_t p = entry % 64u, r = (chunk / tw) * 8u + p / 8u, x = (chunk % tw) * 8u + p % 8u;
+                if (r >= a.num_rows || x >= W) { a.out_rays.U(a.cap, RQ_FLAGS, e) = 8u; continue; }
+                emit(e, r * W + x);
+            } else {
+                emit(e, (uint32_t)u);
+            }
+        }
+        return;
+    }
+    const uint32_t total = a.mode == 0 ? W * a.num_rows : (uint32_t)min(aa_want, (unsigned long long)a.cap);
+    // item i goes to sub-queue i % RT_WF_Q
+    if (blockIdx.x == 0) {
+        for (uint32_t sq = threadIdx.x; sq < RT_WF_Q; sq += blockDim.x) {
+            a.n_out[2 * sq] = total / RT_WF_Q + (sq < total % RT_WF_Q ? 1u : 0u); a.n_out[2 * sq + 1] = 0;
+        }
+    }
+    // thread t writes entry t % per of sub-queue t / per: neighbouring lanes fill neighbouring entries
+    const uint32_t per = (total + RT_WF_Q - 1u) / RT_WF_Q;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < per * RT_WF_Q; t += gridDim.x * blockDim.x) {
+        const uint32_t item = (t % per) * RT_WF_Q + t / per;
+        if (item >= total) continue;
+        emit((item % RT_WF_Q) * a.sub + item / RT_WF_Q, item);
     }
 }
 

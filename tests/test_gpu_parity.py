@@ -267,6 +267,29 @@ def test_chain_count_does_not_change_the_frame(name, width, device_scene, scene_
             assert r["counters"][k] == frames[0]["counters"][k], (name, k)
 
 
+@pytest.mark.parametrize("name,width,height", [("glass_monkey", 333, 217), ("many_balls_forest", 250, 131), ("subtraction_outside1", 203, 99)])
+def test_tile_dealt_generation_zero_does_not_change_the_frame(name, width, height, device_scene, scene_cache, monkeypatch):
+    """Generation 0 dealt out ray by ray, or in tiles of 8 x 8 pixels / runs of 64 AA samples (the default for scenes
+    with a hierarchy over their instances), for either pass or both: the same frame and the same work, also at sizes
+    that leave partial tiles at the frame's edges and with the rows split over three ranks (row lists with halo rows)."""
+    s = scene_cache(name)
+    ds = device_scene(name)
+    for split in ({}, {"rank": 1, "nranks": 3, "tile_rows": 8}):
+        dim, cam, cfg = s.view(width=width, height=height, anti_alias=True, seed=1, **split)
+        frames = []
+        for tiles in ("0", "1", "2", "3"):
+            monkeypatch.setenv("RT_WF_TILES", tiles)
+            frames.append(ds.render(dim, cam, cfg, count_work=True))
+        monkeypatch.delenv("RT_WF_TILES", raising=False)
+        frames.append(ds.render(dim, cam, cfg, count_work=True))          # the scene's default
+        assert frames[0]["counters"]["schedule"] == 1 and frames[0]["counters"]["rays_aa"] > 0
+        for r in frames[1:]:
+            for k in ("color", "hit_id", "distance", "rgb", "aa_mask"):
+                assert np.array_equal(r[k], frames[0][k]), (name, k)
+            for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_aa", "shade_evals", "tri_tests", "box_tests", "instance_tests", "stack_overflows"):
+                assert r["counters"][k] == frames[0]["counters"][k], (name, k)
+
+
 def test_queue_overflow_falls_back_to_the_persistent_kernel(render_mod, scene_cache, monkeypatch):
     s = scene_cache("glass_monkey")
     dim, cam, cfg = small_view(s, 200, anti_alias=True, seed=1)
