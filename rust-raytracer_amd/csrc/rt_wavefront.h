@@ -590,13 +590,18 @@ k_wf_walk(DScene sc, WfArgs a) {
             uint32_t c0, c1;
             if (COUNT) wk.box_tests += 2;
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
+            uint32_t top = 0;
             if (LDS) {
                 float tn0, tn1;
+                // (the stack's top is asked for together with the node: the branch-free step below may need it, and it
+                // does not depend on the box tests)
+                top = lstack3[__mul24(min(max(sp - 1, 0), RT_WF_LDS_STACK - 1), (int)lstride)];
                 const LBvhNode n = lds_node(lnodes + cur);
                 h0 = slab32_box(n.lo[0], n.hi[0], s32, best32, tn0);
                 h1 = slab32_box(n.lo[1], n.hi[1], s32, best32, tn1);
                 c0 = n.child[0]; c1 = n.child[1];
                 swap = tn1 < tn0;
+                asm volatile("" : "+v"(top));                         // (keeps the read where it was written: ahead of the node's)
             } else {
                 double tn0, tn1;
                 const DBvhNode& n = gnodes[cur];
@@ -605,7 +610,17 @@ k_wf_walk(DScene sc, WfArgs a) {
                 c0 = n.child[0]; c1 = n.child[1];
                 swap = tn1 < tn0;
             }
-            if (h0 && h1) {
+            if (LDS && !__ballot(sp >= RT_WF_LDS_STACK)) {
+                // Every lane's stack top lies in LDS (nearly always): the step without branches.  The far child is
+                // stored above the top whether it will be needed or not, the top has been read whether it will be
+                // popped or not, and selects decide.  A wave's step is then one straight run of instructions instead of four nested
+                // divergent regions, each of which costs a round of scalar bookkeeping per trip.
+                lstack3[__mul24(sp, (int)lstride)] = swap ? c0 : c1;
+                const bool both = h0 && h1, none = !h0 && !h1;
+                const uint32_t one = h0 ? c0 : c1;
+                cur = both ? (swap ? c1 : c0) : (none ? (sp > 0 ? top : RT_WALK_DONE) : one);
+                sp += both ? 1 : ((none && sp > 0) ? -1 : 0);
+            } else if (h0 && h1) {
                 cur = swap ? c1 : c0;
                 push(swap ? c0 : c1);
             } else if (h0) cur = c0;

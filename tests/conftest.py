@@ -3,6 +3,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (first: torch and the render library bring their own HIP runtimes, and torch finds no GPU when it is loaded second)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
