@@ -255,6 +255,73 @@ def test_obj_reader_rounds_every_literal_once(render_mod):
     assert np.array_equal(got["positions"].view(np.uint64), want.view(np.uint64))
 
 
+def random_obj(seed):
+    """A random OBJ text: pools that grow between faces, polygons of 3 to 6 corners in all four corner forms,
+    positive and negative indices, repeated corners, groups with and without faces, comments, blank lines, CRLF."""
+    rng = np.random.default_rng(seed)
+    lines, nv, nvt, nvn = [], 0, 0, 0
+    fmt = [b"%.6f", b"%.3f", b"%g", b"%.9e"]
+
+    def num():
+        return fmt[rng.integers(0, len(fmt))] % float(rng.uniform(-5, 5))
+
+    def add_pool(kind, n):
+        nonlocal nv, nvt, nvn
+        for _ in range(n):
+            k = 2 if kind == b"vt" else 3
+            lines.append(kind + b" " + b" ".join(num() for _ in range(k)))
+        if kind == b"v":
+            nv += n
+        elif kind == b"vt":
+            nvt += n
+        else:
+            nvn += n
+    add_pool(b"v", 4)
+    for _ in range(int(rng.integers(20, 120))):
+        what = rng.integers(0, 10)
+        if what == 0:
+            add_pool(b"v", int(rng.integers(1, 6)))
+        elif what == 1:
+            add_pool(b"vt", int(rng.integers(1, 4)))
+        elif what == 2:
+            add_pool(b"vn", int(rng.integers(1, 4)))
+        elif what == 3:
+            lines.append([b"g part", b"o thing", b"# note", b"", b"usemtl m", b"s 1"][rng.integers(0, 6)])
+        else:
+            form = int(rng.integers(0, 4))          # v, v/vt, v//vn, v/vt/vn
+            if form in (1, 3) and nvt == 0:
+                form = 0
+            if form in (2, 3) and nvn == 0:
+                form = 0 if form == 2 else 1
+            if form in (1, 3) and nvt == 0:
+                form = 0
+            corners = []
+            pool = [int(rng.integers(0, nv)) for _ in range(4)]      # few distinct vertices: corners repeat across faces
+            for _ in range(int(rng.integers(3, 7))):
+                def ref(i, n):
+                    return b"%d" % (i + 1 if rng.integers(0, 2) else i - n)
+                iv = pool[rng.integers(0, 4)]
+                t = ref(iv, nv)
+                if form in (1, 3):
+                    t += b"/" + ref(int(rng.integers(0, nvt)), nvt)
+                if form == 2:
+                    t += b"/"
+                if form in (2, 3):
+                    t += b"/" + ref(int(rng.integers(0, nvn)), nvn)
+                corners.append(t)
+            lines.append(b"f " + (b" " if rng.integers(0, 2) else b"\t").join(corners))
+    eol = b"\r\n" if seed % 3 == 0 else b"\n"
+    return eol.join(lines) + (eol if seed % 2 else b"")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_obj_reader_on_random_texts(render_mod, seed):
+    text = random_obj(seed)
+    if b"\nf " not in text:
+        pytest.skip("no face drawn")
+    assert_same_mesh(render_mod.obj_parse(text), sequential_obj(text))
+
+
 def test_obj_reader_errors(render_mod):
     with pytest.raises(render_mod.RtError) as e:
         render_mod.obj_parse(b"v 0 0 0\nv 1 0 0\nv 0 1 0\n")
