@@ -188,6 +188,26 @@ def test_obj_reader_returns_the_mesh_the_harness_reads(render_mod, scene_cache, 
     assert_same_mesh(got, sequential_obj(text))
 
 
+def test_obj_text_to_frame_on_the_device(render_mod, scene_cache, abi_mod):
+    """The whole step before the path on the device: monkey2.obj as text -> rt_obj_parse -> the mesh of glass_monkey's
+    description -> hierarchy built on the device -> the frame the harness-read, host-built scene renders."""
+    s = scene_cache("glass_monkey")
+    src = C.cast(s.desc, C.POINTER(abi_mod.RtSceneDesc)).contents
+    m = render_mod.obj_parse(open(os.path.join(ROOT, "assets", "models", "monkey2.obj"), "rb").read())
+    f64 = np.ascontiguousarray(np.concatenate([m["positions"].reshape(-1), m["normals"].reshape(-1), m["texcoords"].reshape(-1)]))
+    u32 = np.ascontiguousarray(m["faces"].reshape(-1))
+    npos, nnorm, ntex = len(m["positions"]), len(m["normals"]), len(m["texcoords"])
+    mesh = abi_mod.RtMesh(npos, nnorm, ntex, len(m["faces"]), 0, 3 * npos, 3 * npos + 3 * nnorm, 0)
+    desc = abi_mod.RtSceneDesc()
+    C.memmove(C.byref(desc), C.byref(src), C.sizeof(desc))
+    desc.meshes = C.pointer(mesh)
+    desc.mesh_f64_count = f64.size
+    desc.mesh_f64 = f64.ctypes.data_as(C.POINTER(C.c_double))
+    desc.mesh_u32_count = u32.size
+    desc.mesh_u32 = u32.ctypes.data_as(C.POINTER(C.c_uint32))
+    assert_same_frame(frames(render_mod, s, HOST, 240, 180), frames(render_mod, s, DEVICE, 240, 180, desc))
+
+
 TRICKY = b"""# comments, blank lines, CRLF, tabs, quads and a pentagon, negative indices, groups, corners without vt / vn
 mtllib nothing.mtl
 o first
