@@ -756,11 +756,34 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
     const uint32_t rounded = (nq + 63u) & ~63u;                      // whole waves stay in the loop: reservation and accumulation are wave operations
     uint32_t* hits = a.walk_list + (size_t)sq * (2u * a.sub);
     Work<COUNT> wk = {};
+    // Sky-box scenes: what a ray that left the scene sees costs hundreds of instructions (two inverse
+    // trigonometric functions, four texel taps), and such rays are a minority of a wave's queries.  They are
+    // set aside in the wave's own list and looked up 64 at a time, by full waves.
+    uint32_t* pending = reinterpret_cast<uint32_t*>(rt_lds_dynamic + 4u * 640u * 8u) + (threadIdx.x >> 6) * 128u;
+    uint32_t npending = 0;                                            // (the same on every lane of the wave)
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool batch_misses = sc.has_background != 0;
+    auto look_up_sky = [&](bool all) {
+        while (npending >= 64u || (all && npending > 0u)) {
+            const uint32_t take = min(npending, 64u);
+            uint32_t mslot = RT_NO_SLOT;
+            d3 mval = mk3(0.0, 0.0, 0.0);
+            if (lane < take) {
+                const uint32_t mq = pending[npending - take + lane];
+                mslot = a.rays.U(cap, RQ_SLOT, mq);
+                mval = a.rays.ld3(cap, RQ_W, mq) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, mq));
+                if (a.rays.U(cap, RQ_FLAGS, mq) & 1u) { a.distance[mslot] = INFINITY; a.hit_id[mslot] = 0xFFFFFFFFu; }
+            }
+            npending -= take;
+            wave_accumulate(stage, mslot, mval, a.acc, a.acc_flags);
+        }
+    };
     for (uint32_t ql = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; ql < rounded; ql += (gridDim.x / a.sq_count) * blockDim.x) {
         const uint32_t q = sq * a.sub + (ql >= nr ? ql - nr : ql);   // entry of the shadow-test / ray arrays
         uint32_t kind = 0;
         uint32_t cslot = RT_NO_SLOT;                                  // this query's colour term
         d3 cval = mk3(0.0, 0.0, 0.0);
+        bool missed = false;
         if (ql < nq) {
             if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
                 if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
@@ -770,9 +793,12 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
                 }
             } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
                 if (!a.rjobs.U(cap, JQ_FOUND, q)) {
-                    cslot = a.rays.U(cap, RQ_SLOT, q);
-                    cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
-                    if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
+                    if (batch_misses) missed = true;
+                    else {
+                        cslot = a.rays.U(cap, RQ_SLOT, q);
+                        cval = a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, q));
+                        if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
+                    }
                 } else {
                     const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
                     kind = (bounds & 0xFFFFu) ? 2u : 1u;
@@ -784,7 +810,17 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
         if (kind == 1u) hits[at1] = ql;                               // (hits are rays: ql < nr <= sub, and there are at most nr of them)
         if (kind == 2u) hits[a.sub - 1u - at2] = ql;
         wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
+        if (batch_misses) {
+            const unsigned long long mm = __ballot(missed);
+            if (mm) {
+                if (missed) pending[npending + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = q;
+                npending += (uint32_t)__popcll(mm);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                look_up_sky(false);
+            }
+        }
     }
+    if (batch_misses) look_up_sky(true);
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
 
