@@ -103,15 +103,15 @@ hipError_t rt_device_flip_rows(uint8_t* texels, uint32_t row_bytes, uint32_t hei
 struct Workspace {
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
     DeviceBuf queue[2], acc, acc_flags, lane_mem;
-    // queue-pipeline path: rays / shadow tests of two generations, their query records, contributions, walk list
-    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_contrib, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars;
+    // queue-pipeline path: rays / shadow tests of two generations, their query records, walk list
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars;
     uint32_t wf_cap = 0;
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<uint32_t> rows_host;
     uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     std::vector<DeviceBuf*> all() {
         return {&color, &distance, &hit_id, &mask, &list, &samples, &rows, &scalars, &rgb_full, &queue[0], &queue[1], &acc, &acc_flags, &lane_mem,
-                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_contrib, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars};
+                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars};
     }
     void use(Arena* a) { for (DeviceBuf* b : all()) b->arena = a; }
     void release() { for (DeviceBuf* b : all()) b->release(); }
@@ -471,7 +471,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     const uint32_t walk_cus_max = fixed_mem ? std::min(128u, (uint32_t)s->num_cus) : (uint32_t)s->num_cus;
     const size_t walk_overflow_bytes = (size_t)(fixed_mem ? 1u : 4u) * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4u;   // per chain: a walk launch with up to 2048 threads per CU
     const size_t wf_entry_bytes = 2 * (RQ_NF * 8 + RQ_NU * 4) + 2 * (SQ_NF * 8 + SQ_NU * 4) + 2 * (JQ_NF * 8 + JQ_NU * 4) +
-                                  (s->ds.has_background ? CQ_NF * 8 + CQ_NU * 4 : 0) + 2 * sizeof(uint32_t) +
+                                  2 * sizeof(uint32_t) +
                                   ((s->ds.features & RTF_CSG) ? 2 * sizeof(uint32_t) : 0);
     // queue pipeline: s->wf_scale entries per pixel (and queue) of this rank's share, every queue cut into RT_WF_Q sub-queues
     uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)W * num_rows * s->wf_scale, 1u << 20), WF_CAP_MAX);
@@ -570,7 +570,6 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         for (auto& b : w.wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
-        if (s->ds.has_background && (e = w.wf_contrib.ensure(n * (CQ_NF * 8 + CQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
         if ((s->ds.features & RTF_CSG) && (e = w.wf_csg_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
         if ((e = w.wf_overflow.ensure(walk_overflow_bytes)) != RT_OK) return e;
@@ -582,7 +581,6 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         wa.sub = wf_cap / RT_WF_Q; wa.cap = (uint32_t)n;
         wa.csg_list = (uint32_t*)w.wf_csg_list.p;
         wa.walk_list = (uint32_t*)w.wf_walk_list.p; wa.walk_overflow = (uint32_t*)w.wf_overflow.p; wa.refill_min = std::getenv("RT_REFILL_MIN") ? refill_min() : 24u; wa.descend_frac = descend_frac();   // (measured: 24 free lanes before the walk kernel refills, 16 in the persistent kernel)
-        wa.contrib = queue(w.wf_contrib, n, CQ_NF);
         wa.acc = (unsigned long long*)w.acc.p; wa.acc_flags = (uint32_t*)w.acc_flags.p;
         wa.distance = (double*)w.distance.p; wa.hit_id = (uint32_t*)w.hit_id.p; wa.counters = counters;
         wa.dropped = (unsigned int*)s->wf_sticky.p;
@@ -651,10 +649,6 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                 if (lrc != RT_OK) return lrc;
                 lrc = wf_launch(1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
-                if (s->ds.has_background) {
-                    hipLaunchKernelGGL(k_wf_accumulate, dim3(cgrid), dim3(256), 0, cs, wa);
-                    HIP_TRY(hipGetLastError());
-                }
             }
         }
         wa.walk_overflow = overflow0;

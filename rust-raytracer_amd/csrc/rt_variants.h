@@ -73,6 +73,7 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
     const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
     uint32_t lds = tables;
     if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
+    if (which == 0 && ds.has_background) lds = tables + 4u * 640u * 8u + 4u * 128u * 4u;   // + staging and the waves' lists of rays that only see the sky box
     if (which == 2) lds = 4u * 640u * 8u + 4u * 128u * 4u;            // staging + the waves' lists of rays that left the scene
     const void* fn = nullptr;
     if (which == 0) fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, false> : (const void*)k_wf_analytic<F, false, true, false>)

@@ -13,7 +13,7 @@
 //     k_wf_shade      one thread per listed hit: hit -> world space, shader tree, new rays and
 //                     shadow tests appended to the next generation's queues, the hit's own
 //                     colour term to the accumulators
-// (sky-box scenes add k_wf_accumulate for the background seen by rays that failed the gate).
+// (in sky-box scenes rays that failed the gate still see the background: the analytic kernel looks it up).
 // Every lane of every kernel has a query of the same kind to work on, each kernel only holds
 // the registers its phase needs (more waves per SIMD to hide the queue traffic), and the walk
 // draws on millions of queries so that one long walk no longer holds up a wave.
@@ -72,8 +72,6 @@ enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH
 enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
 // query records (TraceJob): 2 doubles, 5 words
 enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
-// colour terms of the analytic phase (sky-box scenes): 3 doubles, 1 word (slot, RT_NO_SLOT: nothing), one per ray entry
-enum { CQ_C = 0, CQ_NF = 3, CQ_SLOT = 0, CQ_NU = 1 };
 
 struct WfArgs {
     // queries of the current generation; sub-queue s holds rays [s*sub, s*sub + n_in[2s]) and
@@ -106,7 +104,6 @@ struct WfArgs {
     uint32_t refill_min;
     uint32_t descend_frac;            // eighths: the descent pauses for the leaves once fewer than this share of the walking lanes still descend (0: never)
     // outputs
-    WfQueue contrib;                  // cap entries
     unsigned long long* acc;
     uint32_t* acc_flags;
     double* distance;
@@ -122,6 +119,8 @@ struct WfArgs {
     uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
     uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
 };
+
+RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags);   // (below, with the shading phase)
 
 // The shader tree's rays go straight into the next generation's queues, at positions reserved beforehand.
 struct QueueSink {
@@ -307,21 +306,22 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
     const uint32_t* clist = a.csg_list + (size_t)sq * (2u * a.sub);
-    for (uint32_t wi = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; wi < nwork; wi += (gridDim.x / a.sq_count) * blockDim.x) {
+    // One query (the body of the loop below).  Returns the entry of a ray that failed the gate of Scene::cast_ray in a
+    // sky-box scene (what it sees is looked up afterwards), else RT_NO_SLOT.
+    auto one_query = [&](uint32_t wi) -> uint32_t {
         uint32_t ql = wi;
         if constexpr (REDO) {
-            if (wi >= n0 && wi < r0) continue;
+            if (wi >= n0 && wi < r0) return RT_NO_SLOT;
             const uint32_t e = wi < n0 ? clist[wi] : clist[2u * a.sub - 1u - (wi - r0)];
             ql = (e & 0x80000000u) ? nr + (e & 0x7FFFFFFFu) - sq * a.sub : e - sq * a.sub;
         }
         if (!REDO) {
             if (ql < nr) {
                 const uint32_t q = sq * a.sub + ql;
-                if (sc.has_background) a.contrib.U(cap, CQ_SLOT, q) = RT_NO_SLOT;   // (only sky-box scenes queue rays that fail the gate)
-                if (a.rays.U(cap, RQ_FLAGS, q) & 8u) { a.rjobs.U(cap, JQ_FLAGS, q) = 6u; continue; }        // a hole (queue overflow only)
+                if (a.rays.U(cap, RQ_FLAGS, q) & 8u) { a.rjobs.U(cap, JQ_FLAGS, q) = 6u; return RT_NO_SLOT; }        // a hole (queue overflow only)
             } else {
                 const uint32_t q = sq * a.sub + ql - nr;
-                if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { a.sjobs.U(cap, JQ_FLAGS, q) = 7u; continue; }   // a hole
+                if (a.shadows.U(cap, SQ_SLOT, q) == RT_NO_SLOT) { a.sjobs.U(cap, JQ_FLAGS, q) = 7u; return RT_NO_SLOT; }   // a hole
             }
         }
         const bool shadow = ql >= nr;
@@ -344,15 +344,10 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
             d3 rc = mk3(1.0, 1.0, 1.0);
             if (gated) rc = a.rays.ld3(cap, RQ_C, q);
             if (gated && !(a.rays.U(cap, RQ_DEPTH, q) > 0 && (rc.x + rc.y + rc.z) > RT_MIN_CONTRIBUTION)) {
-                const uint32_t slot = a.rays.U(cap, RQ_SLOT, q);
-                // its colour term: the background (k_wf_accumulate adds it); exactly nothing without a sky box
-                if (sc.has_background) {
-                    a.contrib.U(cap, CQ_SLOT, q) = slot;
-                    a.contrib.st3(cap, CQ_C, q, a.rays.ld3(cap, RQ_W, q) * background_color<F>(sc, d));
-                }
-                if (flags & 1u) { a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
+                // its colour term: the background, looked up below by full waves; exactly nothing without a sky box
+                if (flags & 1u) { const uint32_t slot = a.rays.U(cap, RQ_SLOT, q); a.distance[slot] = INFINITY; a.hit_id[slot] = 0xFFFFFFFFu; }
                 jobs.U(cap, JQ_FLAGS, q) = 6u;
-                continue;
+                return ((F & RTF_IMAGES) != 0 && sc.has_background) ? q : RT_NO_SLOT;
             }
             if (COUNT) { if (flags & 2u) cam++; else wk.rays_secondary++; }
         }
@@ -367,7 +362,7 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
                 const uint32_t e = shadow ? (q | 0x80000000u) : q;
                 if (deferred == 1u) list[wave_alloc(a.csg_count + 2 * sq)] = e;
                 else list[2u * a.sub - 1u - wave_alloc(a.csg_count + 2 * sq + 1)] = e;
-                continue;
+                return RT_NO_SLOT;
             }
         }
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
@@ -400,7 +395,46 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
                 a.walk_list[(size_t)sq * (2u * a.sub) + w] = shadow ? (q | 0x80000000u) : q;
             }
         }
+        return RT_NO_SLOT;
+    };
+    // Sky-box scenes queue the rays that fail the gate: they still see the background (scene.rs:67-73).  That lookup costs
+    // hundreds of instructions and concerns a minority of a wave's queries, so those rays are set aside in the wave's own
+    // list and looked up 64 at a time by full waves, their terms going straight to the accumulators.
+    // LDS behind the tables: [per wave 64 x 10 words of staging][per wave 128 list entries]
+    const bool sky = !REDO && (F & RTF_IMAGES) != 0 && sc.has_background != 0;   // (a variant without images has no sky box: none of this is compiled into it)
+    uint8_t* sky_lds = rt_lds_dynamic + (HOT ? (gsc.hot_bytes + 15u) & ~15u : 0u);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(sky_lds) + (threadIdx.x >> 6) * 640u;
+    uint32_t* pending = reinterpret_cast<uint32_t*>(sky_lds + 4u * 640u * 8u) + (threadIdx.x >> 6) * 128u;
+    uint32_t npending = 0;                                            // (the same on every lane of the wave)
+    const uint32_t lane = threadIdx.x & 63u;
+    auto look_up_sky = [&](bool all) {
+        while (npending >= 64u || (all && npending > 0u)) {
+            const uint32_t take = min(npending, 64u);
+            uint32_t mslot = RT_NO_SLOT;
+            d3 mval = mk3(0.0, 0.0, 0.0);
+            if (lane < take) {
+                const uint32_t mq = pending[npending - take + lane];
+                mslot = a.rays.U(cap, RQ_SLOT, mq);
+                mval = a.rays.ld3(cap, RQ_W, mq) * background_color<F>(sc, a.rays.ld3(cap, RQ_D, mq));
+            }
+            npending -= take;
+            wave_accumulate(stage, mslot, mval, a.acc, a.acc_flags);
+        }
+    };
+    const uint32_t bound = sky ? (nwork + 63u) & ~63u : nwork;       // (whole waves stay in the loop when they share a list)
+    for (uint32_t wi = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; wi < bound; wi += (gridDim.x / a.sq_count) * blockDim.x) {
+        const uint32_t sky_q = wi < nwork ? one_query(wi) : RT_NO_SLOT;
+        if (sky) {
+            const unsigned long long mm = __ballot(sky_q != RT_NO_SLOT);
+            if (mm) {
+                if (sky_q != RT_NO_SLOT) pending[npending + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = sky_q;
+                npending += (uint32_t)__popcll(mm);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                look_up_sky(false);
+            }
+        }
     }
+    if (sky) look_up_sky(true);
     wf_flush<COUNT>(a.counters, wk, cam, a.mode);
 }
 
@@ -762,7 +796,7 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
     uint32_t* pending = reinterpret_cast<uint32_t*>(rt_lds_dynamic + 4u * 640u * 8u) + (threadIdx.x >> 6) * 128u;
     uint32_t npending = 0;                                            // (the same on every lane of the wave)
     const uint32_t lane = threadIdx.x & 63u;
-    const bool batch_misses = sc.has_background != 0;
+    const bool batch_misses = (F & RTF_IMAGES) != 0 && sc.has_background != 0;
     auto look_up_sky = [&](bool all) {
         while (npending >= 64u || (all && npending > 0u)) {
             const uint32_t take = min(npending, 64u);
@@ -911,36 +945,3 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
-
-// ------------------------------------------------------------------ accumulation of the analytic phase's terms
-#ifdef RT_FRAME_KERNELS
-// Sky-box scenes only: the background seen by rays that failed the cast_ray gate (k_wf_analytic).
-// One thread per (ray, limb): the nine limbs of one sample are adjacent words.
-__global__ void __launch_bounds__(256)
-k_wf_accumulate(WfArgs a) {
-    const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
-    const uint32_t nr = min(a.n_in[2 * sq], a.sub);
-    const uint32_t tasks = nr * RT_ACC_LIMBS;
-    for (uint32_t t = (blockIdx.x / a.sq_count) * blockDim.x + threadIdx.x; t < tasks; t += (gridDim.x / a.sq_count) * blockDim.x) {
-        const uint32_t ql = t / RT_ACC_LIMBS, limb = t % RT_ACC_LIMBS;
-        const uint32_t e = sq * a.sub + ql;
-        const uint32_t slot = a.contrib.U(a.cap, CQ_SLOT, e);
-        if (slot == RT_NO_SLOT) continue;
-        const uint32_t channel = limb / 3u, part = limb % 3u;
-        const double v = a.contrib.F(a.cap, CQ_C + channel, e);
-        if (!(fabs(v) < 0x1p40)) {
-            if (part == 0) {
-                uint32_t bit = (v != v) ? 4u : (v > 0.0 ? 1u : 2u);
-                atomicOr(a.acc_flags + slot, bit << (3u * channel));
-            }
-            continue;
-        }
-        double l0 = trunc(v);
-        double r1 = (v - l0) * 0x1p40;
-        double l1 = trunc(r1);
-        double l2 = trunc((r1 - l1) * 0x1p40);
-        double l = part == 0 ? l0 : (part == 1 ? l1 : l2);
-        if (l != 0.0) atomicAdd(a.acc + (size_t)slot * RT_ACC_LIMBS + limb, (unsigned long long)(long long)l);
-    }
-}
-#endif  // RT_FRAME_KERNELS
