@@ -290,6 +290,26 @@ def test_tile_dealt_generation_zero_does_not_change_the_frame(name, width, heigh
                 assert r["counters"][k] == frames[0]["counters"][k], (name, k)
 
 
+@pytest.mark.parametrize("width,height", [(1, 1), (3, 1), (7, 5), (9, 3), (65, 2)])
+def test_tiny_frames_of_a_scene_with_an_instance_hierarchy(width, height, device_scene, scene_cache, oracle, monkeypatch):
+    """Frames smaller than one 8 x 8 tile, or one tile and a bit: tile-dealt generation 0 (the default of
+    many_balls_forest) against ray-by-ray dealing and against the oracle."""
+    s = scene_cache("many_balls_forest")
+    ds = device_scene("many_balls_forest")
+    dim, cam, cfg = s.view(width=width, height=height, anti_alias=True, seed=1)
+    got = ds.render(dim, cam, cfg, count_work=True)
+    monkeypatch.setenv("RT_WF_TILES", "0")
+    plain = ds.render(dim, cam, cfg, count_work=True)
+    monkeypatch.delenv("RT_WF_TILES", raising=False)
+    for k in ("color", "hit_id", "distance", "rgb", "aa_mask"):
+        assert np.array_equal(got[k], plain[k]), k
+    assert got["counters"]["rays_total"] == plain["counters"]["rays_total"]
+    want = oracle.render(s, dim, cam, cfg)
+    assert np.array_equal(got["hit_id"], want["hit_id"])
+    assert np.abs(got["rgb"].astype(int) - want["rgb"].astype(int)).max() <= 1
+    assert got["counters"]["rays_primary"] == want["counters"]["rays_primary"] == width * height
+
+
 def test_queue_overflow_falls_back_to_the_persistent_kernel(render_mod, scene_cache, monkeypatch):
     s = scene_cache("glass_monkey")
     dim, cam, cfg = small_view(s, 200, anti_alias=True, seed=1)
