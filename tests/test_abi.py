@@ -51,3 +51,15 @@ def test_host_library_scene_registry(scenes_mod):
     for required in ["basic_setup_scene", "plane_test_1", "shadow_test_1", "light_room", "glass_monkey",
                      "many_balls", "many_balls_forest", "subtraction_outside1"]:
         assert required in names
+
+
+def test_entry_point_modules_resolve():
+    """Everything __graft_entry__.smoke() imports must be importable here too (it only runs on the GPU box)."""
+    import importlib
+    import re
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    names = re.findall(r'import_module\("([^"]+)"\)', src)
+    assert "harness.scenes" in names and "rust-raytracer_amd.render" in names
+    for n in names:
+        importlib.import_module(n)
+    from oracle import binding  # noqa: F401
