@@ -349,3 +349,9 @@ def test_obj_reader_errors(render_mod):
     with pytest.raises(render_mod.RtError) as e:
         render_mod.obj_parse(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n")
     assert e.value.code == 1
+
+
+def test_unknown_ingest_mode_is_refused(render_mod, scene_cache):
+    with pytest.raises(render_mod.RtError) as e:
+        render_mod.DeviceScene(scene_cache("glass_monkey"), device=0, ingest=7)
+    assert e.value.code == 1 and "ingest" in str(e.value)
