@@ -56,7 +56,7 @@ def build_hip(force=False, jobs=None):
         with ThreadPoolExecutor(max_workers=jobs) as pool:
             list(pool.map(_run, todo))
     if todo or _newer(HIP_LIB, objects):
-        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objects, "-lz"])   # zlib: the PNG writer's deflate
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objects, "-lz", "-pthread"])   # zlib: the PNG writer's deflate (in bands, on host threads)
     return HIP_LIB
 
 
