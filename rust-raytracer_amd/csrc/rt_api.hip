@@ -4,6 +4,7 @@
 // (src/render.rs:158,237) by one immutable device copy.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -194,6 +195,7 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
         if (on_device) fs.mesh_builder = rt_device_mesh_builder(device);
         fs.flip_on_device = ingest == RT_INGEST_DEVICE || (ingest == RT_INGEST_AUTO && desc->texel_bytes >= (1u << 20));
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     try {
         rtflat::flatten(*desc, fs);
     } catch (const rtflat::Unsupported& e) {
@@ -201,6 +203,7 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     } catch (const std::exception& e) {
         return fail(RT_ERR_INVALID_ARG, e.what());
     }
+    const auto t_flat = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(device));
     { int sr = scratch_lookup(device); if (sr != RT_OK) return sr; }
     RtScene* s = new (std::nothrow) RtScene();
@@ -274,6 +277,11 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     if (s->wf_sticky.ensure(16) != RT_OK || hipMemset(s->wf_sticky.p, 0, 16) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipMalloc failed"); }
     if (hipHostMalloc((void**)&s->h_dropped, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_DEVICE, "hipHostMalloc failed"); }
     *s->h_dropped = 0;
+    if (std::getenv("RT_DEBUG_INGEST")) {
+        (void)hipDeviceSynchronize();
+        std::fprintf(stderr, "[rt] scene create: flatten %.2f ms, total %.2f ms\n", std::chrono::duration<double, std::milli>(t_flat - t_begin).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    }
     *out = s;
     return RT_OK;
 }

@@ -108,6 +108,8 @@ inline V3 normalize(V3 a) { return a * (1.0 / length(a)); }
 inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 
 // ---- the flattened scene (host copies; uploaded verbatim) ----
+constexpr size_t RT_LDS_BLOB_MAX = 160u * 1024u;   // no CU holds more LDS than this: meshes beyond it are never walked out of LDS
+
 // What a bounding-hierarchy build works on and produces: per triangle its box, the box's centre and the face it
 // came from (in the order the leaves hold them); per node its box, its children (or -1) and its range of triangles.
 struct BuildTri { V3 lo, hi, c; uint32_t face; };
@@ -265,6 +267,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     for (int k = 0; k < 3; ++k) dm.max_abs = std::max(dm.max_abs, std::max(std::fabs(dm.lo[k]), std::fabs(dm.hi[k])));
     dm.max_abs *= 1.0 + 1e-6;   // (the f32 copies of the boxes are rounded outward by up to 2^-23 of their value)
     // triangles in BVH order; derived values as Mesh::from_path computes them (mesh.rs:396-404)
+    fs.mesh_tris.reserve(fs.mesh_tris.size() + m.num_faces);
     for (uint32_t i = 0; i < m.num_faces; ++i) {
         uint32_t f = bt[i].face;
         V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
@@ -311,8 +314,10 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     dm.uv_off = (uint32_t)(fs.mesh_uvs.size() / 2);
     dm.num_uvs = m.num_texcoords;
     fs.mesh_uvs.insert(fs.mesh_uvs.end(), d.mesh_f64 + m.texcoords_off, d.mesh_f64 + m.texcoords_off + 2 * (size_t)m.num_texcoords);
-    // LDS copies: f32 boxes rounded outward, triangles without indices
-    {
+    // LDS copies: f32 boxes rounded outward, triangles without indices (only while the scene's meshes can still fit
+    // a CU's LDS together: a larger scene walks the f64 records in global memory and needs no copies)
+    if (fs.lds_blob.size() + ((size_t)dm.num_nodes + dm.num_tris) * 64u > RT_LDS_BLOB_MAX) { fs.lds_exact = false; fs.lds_blob.clear(); }
+    else if (fs.lds_exact) {
         auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
         auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
         while (fs.lds_blob.size() % 16) fs.lds_blob.push_back(0);
@@ -328,6 +333,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
             fs.lds_blob.insert(fs.lds_blob.end(), b, b + sizeof l);
         }
         dm.lds_tri_off = (uint32_t)fs.lds_blob.size();
+        fs.lds_blob.reserve(fs.lds_blob.size() + (size_t)dm.num_tris * sizeof(LMeshTri));
         for (uint32_t i = 0; i < dm.num_tris; ++i) {
             const DMeshTri& t = fs.mesh_tris[dm.tri_off + i];
             LMeshTri l{};

@@ -16,7 +16,9 @@
 //           builder's order (the sweep), so the tree is the host builder's tree, node for node.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -142,13 +144,14 @@ __device__ inline double key_value(unsigned long long k) {
     const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
     return __longlong_as_double((long long)b);
 }
-__device__ inline double block_reduce(double v, bool take_min, double* lds) {   // 256 threads; the result on every thread
+__device__ inline double block_reduce(double v, bool take_min, double* lds) {   // up to 16 waves; the result on every thread
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(v, off); v = take_min ? fmin(v, o) : fmax(v, o); }
     __syncthreads();
     if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
-    const double a = take_min ? fmin(lds[0], lds[1]) : fmax(lds[0], lds[1]), b = take_min ? fmin(lds[2], lds[3]) : fmax(lds[2], lds[3]);
-    return take_min ? fmin(a, b) : fmax(a, b);
+    double r = lds[0];
+    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) r = take_min ? fmin(r, lds[w]) : fmax(r, lds[w]);
+    return r;
 }
 __device__ inline double box_area(const double* lo, const double* hi) {
     const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -158,14 +161,15 @@ __device__ inline double box_area(const double* lo, const double* hi) {
 // One workgroup per node of the level [level_start, level_start + gridDim.x).  Reads the node's triangles from
 // `src`; a leaf writes their faces to `order` (its final place), an inner node writes them partitioned to `dst`
 // and appends its two children to `nodes`.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes, uint32_t level_start, uint32_t node_cap,
               uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ unsigned long long blo[3][BINS][3], bhi[3][BINS][3];
     __shared__ unsigned int bcount[3][BINS];
     __shared__ int s_axis, s_bin;
-    __shared__ unsigned int s_left, wl[4], wr[4];
+    __shared__ unsigned int s_left, wl[16], wr[16];
+    const uint32_t nwaves = blockDim.x >> 6;
     GNode& nd = nodes[level_start + blockIdx.x];
     const uint32_t first = nd.first, count = nd.count, depth = nd.depth;
     const double inf = INFINITY;
@@ -257,7 +261,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
             if (lane == 0) { wl[wave] = (unsigned int)__popcll(ml); wr[wave] = (unsigned int)__popcll(mr); }
             __syncthreads();
             uint32_t bl = 0, br = 0, tl = 0, tr = 0;
-            for (uint32_t w = 0; w < 4; ++w) { if (w < wave) { bl += wl[w]; br += wr[w]; } tl += wl[w]; tr += wr[w]; }
+            for (uint32_t w = 0; w < nwaves; ++w) { if (w < wave) { bl += wl[w]; br += wr[w]; } tl += wl[w]; tr += wr[w]; }
             if (valid) {
                 const uint32_t at = left ? run_left + bl + (uint32_t)__popcll(ml & lt) : n_left + run_right + br + (uint32_t)__popcll(mr & lt);
                 dst[first + at] = t;
@@ -281,6 +285,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
 
 void device_build(int device, const double* P, uint32_t npos, const uint32_t* F, uint32_t nfaces, int max_depth,
                   std::vector<rtflat::BuildTri>& bt, std::vector<rtflat::BuildNode>& bn) {
+    const auto t_begin = std::chrono::steady_clock::now();
     try {
         ING_HIP(hipSetDevice(device));
         Pool pool;
@@ -303,7 +308,10 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
         uint32_t level_start = 0, level_end = 1;
         int from = 0;
         while (level_end > level_start) {
-            hipLaunchKernelGGL(k_build_level, dim3(level_end - level_start), dim3(256), 0, st, tri[from], tri[1 - from], nodes, level_start, node_cap,
+            // (the first levels hold few nodes with many triangles each: large workgroups there, small ones below)
+            const uint32_t level_nodes = level_end - level_start;
+            const uint32_t block = (uint64_t)level_nodes * 2048u <= nfaces ? 1024u : ((uint64_t)level_nodes * 512u <= nfaces ? 512u : 256u);
+            hipLaunchKernelGGL(k_build_level, dim3(level_nodes), dim3(block), 0, st, tri[from], tri[1 - from], nodes, level_start, node_cap,
                                scalars, order, max_depth, scalars + 1);
             ING_HIP(hipGetLastError());
             uint32_t now[2];
@@ -314,26 +322,36 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
             level_start = level_end; level_end = std::min(now[0], node_cap);
             from = 1 - from;
         }
+        const auto t_levels = std::chrono::steady_clock::now();
         std::vector<GNode> g(level_end);
         std::vector<uint32_t> ord(nfaces);
         ING_HIP(hipMemcpy(g.data(), nodes, g.size() * sizeof(GNode), hipMemcpyDeviceToHost));
         ING_HIP(hipMemcpy(ord.data(), order, ord.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const auto t_copied = std::chrono::steady_clock::now();
         // nodes renumbered in the order the host builder's recursion creates them (children allocated before descending)
         bt.assign(nfaces, rtflat::BuildTri{});
         for (uint32_t i = 0; i < nfaces; ++i) bt[i].face = ord[i];
-        bn.assign(1, rtflat::BuildNode{});
-        bn.reserve(g.size());
-        std::function<void(int, uint32_t)> place = [&](int at, uint32_t gi) {
-            const GNode& n = g[gi];
+        // (the recursion "allocate both children, descend left, descend right" with a stack of its own: the right child waits on it)
+        bn.assign(g.size(), rtflat::BuildNode{});
+        std::vector<std::pair<int, uint32_t>> todo;              // (index in bn, index in g)
+        todo.reserve(64);
+        todo.emplace_back(0, 0u);
+        int next = 1;
+        while (!todo.empty()) {
+            const int at = todo.back().first;
+            const GNode& n = g[todo.back().second];
+            todo.pop_back();
             bn[at].lo = {n.lo[0], n.lo[1], n.lo[2]}; bn[at].hi = {n.hi[0], n.hi[1], n.hi[2]};
-            if (n.left < 0) { bn[at].first = n.first; bn[at].count = n.count; return; }
-            const int l = (int)bn.size(); bn.emplace_back();
-            const int r = (int)bn.size(); bn.emplace_back();
+            if (n.left < 0) { bn[at].first = n.first; bn[at].count = n.count; continue; }
+            const int l = next++, r = next++;
             bn[at].left = l; bn[at].right = r;
-            place(l, (uint32_t)n.left);
-            place(r, (uint32_t)n.right);
-        };
-        place(0, 0);
+            todo.emplace_back(r, (uint32_t)n.right);
+            todo.emplace_back(l, (uint32_t)n.left);
+        }
+        if (std::getenv("RT_DEBUG_INGEST"))
+            std::fprintf(stderr, "[rt] device hierarchy build: %u faces, %zu nodes, levels %.2f ms, copies back %.2f ms, renumbering %.2f ms\n", nfaces, g.size(),
+                         std::chrono::duration<double, std::milli>(t_levels - t_begin).count(), std::chrono::duration<double, std::milli>(t_copied - t_levels).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copied).count());
     } catch (const HipFailure& e) {
         throw std::runtime_error("device hierarchy build: " + e.what);
     }
