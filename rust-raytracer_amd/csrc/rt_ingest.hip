@@ -158,12 +158,121 @@ __device__ inline double box_area(const double* lo, const double* hi) {
     return 2.0 * (dx * dy + dy * dz + dz * dx);
 }
 
+// The sweep over the bins of the three axes, in the host builder's order of evaluation (rt_flatten.hpp, build_bvh):
+// the first split of least cost in (axis, bin) order, or axis -1 when no axis has an extent.
+__device__ inline void sweep_bins(const unsigned long long (*blo)[BINS][3], const unsigned long long (*bhi)[BINS][3], const unsigned int (*bcount)[BINS],
+                                  const double* clo, const double* chi, int& out_axis, int& out_bin) {
+    const double inf = INFINITY;
+    double best_cost = inf; int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; ++a) {
+        if (!(chi[a] > clo[a])) continue;
+        double right_area[BINS]; uint32_t right_n[BINS];
+        double rl[3] = {inf, inf, inf}, rh[3] = {-inf, -inf, -inf}; uint32_t rn = 0;
+        for (int b = BINS - 1; b > 0; --b) {
+            rn += bcount[a][b];
+            for (int k = 0; k < 3; ++k) { rl[k] = fmin(rl[k], key_value(blo[a][b][k])); rh[k] = fmax(rh[k], key_value(bhi[a][b][k])); }
+            right_area[b] = rn ? box_area(rl, rh) : 0.0; right_n[b] = rn;
+        }
+        double ll[3] = {inf, inf, inf}, lh[3] = {-inf, -inf, -inf}; uint32_t ln = 0;
+        for (int b = 0; b < BINS - 1; ++b) {
+            ln += bcount[a][b];
+            for (int k = 0; k < 3; ++k) { ll[k] = fmin(ll[k], key_value(blo[a][b][k])); lh[k] = fmax(lh[k], key_value(bhi[a][b][k])); }
+            if (ln == 0 || right_n[b + 1] == 0) continue;
+            const double cost = ln * box_area(ll, lh) + right_n[b + 1] * right_area[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+        }
+    }
+    out_axis = best_axis; out_bin = best_bin;
+}
+
+// Nodes of at most 64 triangles (most nodes of a hierarchy): one wave per node, four nodes per workgroup, a triangle
+// per lane, no workgroup barriers.  Same steps, same arithmetic and same order as k_build_level, which leaves these
+// nodes alone when `small_apart` is set.
+__global__ void __launch_bounds__(256)
+k_build_level_small(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes, uint32_t level_start, uint32_t level_end, uint32_t node_cap,
+                    uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error) {
+    __shared__ unsigned long long blo_all[4][3][BINS][3], bhi_all[4][3][BINS][3];
+    __shared__ unsigned int bcount_all[4][3][BINS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t ni = level_start + blockIdx.x * 4u + wave;
+    if (ni >= level_end) return;
+    GNode& nd = nodes[ni];
+    const uint32_t first = nd.first, count = nd.count, depth = nd.depth;
+    if (count > 64u) return;
+    unsigned long long (*blo)[BINS][3] = blo_all[wave];
+    unsigned long long (*bhi)[BINS][3] = bhi_all[wave];
+    unsigned int (*bcount)[BINS] = bcount_all[wave];
+    const double inf = INFINITY;
+    const bool mine = lane < count;
+    GTri t{};
+    if (mine) t = src[first + lane];
+    double lo[3], hi[3], clo[3], chi[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = mine ? t.lo[k] : inf; hi[k] = mine ? t.hi[k] : -inf; clo[k] = mine ? t.c[k] : inf; chi[k] = mine ? t.c[k] : -inf;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fmin(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], off));
+            clo[k] = fmin(clo[k], __shfl_xor(clo[k], off)); chi[k] = fmax(chi[k], __shfl_xor(chi[k], off));
+        }
+    }
+    if (lane == 0) for (int k = 0; k < 3; ++k) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+    if (count <= LEAF || (int)depth >= max_depth) {
+        if (count > LEAF && count > 7u && lane == 0) atomicOr(error, 1u);
+        if (mine) order[first + lane] = t.face;
+        if (lane == 0) { nd.left = -1; nd.right = -1; }
+        return;
+    }
+    for (uint32_t i = lane; i < 3 * BINS; i += 64u) {
+        bcount[i / BINS][i % BINS] = 0;
+        for (int k = 0; k < 3; ++k) { blo[i / BINS][i % BINS][k] = order_key(inf); bhi[i / BINS][i % BINS][k] = order_key(-inf); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double scale[3];
+    for (int a = 0; a < 3; ++a) scale[a] = chi[a] > clo[a] ? (double)BINS / (chi[a] - clo[a]) : 0.0;
+    if (mine) {
+        for (int a = 0; a < 3; ++a) {
+            if (!(chi[a] > clo[a])) continue;
+            const int b = min(BINS - 1, (int)((t.c[a] - clo[a]) * scale[a]));
+            atomicAdd(&bcount[a][b], 1u);
+            for (int k = 0; k < 3; ++k) { atomicMin(&blo[a][b][k], order_key(t.lo[k])); atomicMax(&bhi[a][b][k], order_key(t.hi[k])); }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int axis = -1, bin = -1;
+    if (lane == 0) sweep_bins(blo, bhi, bcount, clo, chi, axis, bin);
+    axis = __shfl(axis, 0); bin = __shfl(bin, 0);
+    uint32_t mid;
+    if (axis < 0) {
+        mid = first + count / 2;
+        if (mine) dst[first + lane] = t;
+    } else {
+        const bool left = mine && min(BINS - 1, (int)((t.c[axis] - clo[axis]) * scale[axis])) <= bin;
+        const unsigned long long ml = __ballot(left), mr = __ballot(mine && !left), lt = (1ull << lane) - 1ull;
+        const uint32_t n_left = (uint32_t)__popcll(ml);
+        if (mine) dst[first + (left ? (uint32_t)__popcll(ml & lt) : n_left + (uint32_t)__popcll(mr & lt))] = t;
+        mid = first + n_left;
+        if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    if (lane == 0) {
+        const uint32_t c = atomicAdd(node_count, 2u);
+        if (c + 2u > node_cap) { atomicOr(error, 2u); nd.left = -1; nd.right = -1; return; }
+        GNode l{}, r{};
+        l.first = first; l.count = mid - first; l.depth = depth + 1; l.left = l.right = -1;
+        r.first = mid; r.count = first + count - mid; r.depth = depth + 1; r.left = r.right = -1;
+        nodes[c] = l; nodes[c + 1] = r;
+        nd.left = (int)c; nd.right = (int)(c + 1);
+        const uint32_t large = (l.count > 64u ? 1u : 0u) + (r.count > 64u ? 1u : 0u);
+        if (large) atomicAdd(node_count + 2, large);             // (nodes of the next level that k_build_level has to take)
+    }
+}
+
 // One workgroup per node of the level [level_start, level_start + gridDim.x).  Reads the node's triangles from
 // `src`; a leaf writes their faces to `order` (its final place), an inner node writes them partitioned to `dst`
 // and appends its two children to `nodes`.
 __global__ void __launch_bounds__(1024)
 k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes, uint32_t level_start, uint32_t node_cap,
-              uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error) {
+              uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error, uint32_t small_apart) {
     __shared__ double red[16];
     __shared__ unsigned long long blo[3][BINS][3], bhi[3][BINS][3];
     __shared__ unsigned int bcount[3][BINS];
@@ -172,6 +281,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
     const uint32_t nwaves = blockDim.x >> 6;
     GNode& nd = nodes[level_start + blockIdx.x];
     const uint32_t first = nd.first, count = nd.count, depth = nd.depth;
+    if (small_apart && count <= 64u) return;                      // k_build_level_small's
     const double inf = INFINITY;
     double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, clo[3] = {inf, inf, inf}, chi[3] = {-inf, -inf, -inf};
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
@@ -210,26 +320,9 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {           // the sweep, in the host builder's order of evaluation
-        double best_cost = inf; int best_axis = -1, best_bin = -1;
-        for (int a = 0; a < 3; ++a) {
-            if (!(chi[a] > clo[a])) continue;
-            double right_area[BINS]; uint32_t right_n[BINS];
-            double rl[3] = {inf, inf, inf}, rh[3] = {-inf, -inf, -inf}; uint32_t rn = 0;
-            for (int b = BINS - 1; b > 0; --b) {
-                rn += bcount[a][b];
-                for (int k = 0; k < 3; ++k) { rl[k] = fmin(rl[k], key_value(blo[a][b][k])); rh[k] = fmax(rh[k], key_value(bhi[a][b][k])); }
-                right_area[b] = rn ? box_area(rl, rh) : 0.0; right_n[b] = rn;
-            }
-            double ll[3] = {inf, inf, inf}, lh[3] = {-inf, -inf, -inf}; uint32_t ln = 0;
-            for (int b = 0; b < BINS - 1; ++b) {
-                ln += bcount[a][b];
-                for (int k = 0; k < 3; ++k) { ll[k] = fmin(ll[k], key_value(blo[a][b][k])); lh[k] = fmax(lh[k], key_value(bhi[a][b][k])); }
-                if (ln == 0 || right_n[b + 1] == 0) continue;
-                const double cost = ln * box_area(ll, lh) + right_n[b + 1] * right_area[b + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
-            }
-        }
+    if (threadIdx.x == 0) {
+        int best_axis, best_bin;
+        sweep_bins(blo, bhi, bcount, clo, chi, best_axis, best_bin);
         s_axis = best_axis; s_bin = best_bin; s_left = 0;
     }
     __syncthreads();
@@ -280,6 +373,8 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
         r.first = mid; r.count = first + count - mid; r.depth = depth + 1; r.left = r.right = -1;
         nodes[c] = l; nodes[c + 1] = r;
         nd.left = (int)c; nd.right = (int)(c + 1);
+        const uint32_t large = (l.count > 64u ? 1u : 0u) + (r.count > 64u ? 1u : 0u);
+        if (large) atomicAdd(node_count + 2, large);             // (nodes of the next level that k_build_level has to take)
     }
 }
 
@@ -298,11 +393,12 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
         const uint32_t node_cap = 2 * nfaces + 2;
         GNode* nodes = pool.get<GNode>(node_cap);
         uint32_t* order = pool.get<uint32_t>(nfaces);
-        uint32_t* scalars = pool.get<uint32_t>(2);          // node count, error bits
+        uint32_t* scalars = pool.get<uint32_t>(3);          // node count, error bits, large nodes of the next level
         hipLaunchKernelGGL(k_tri_boxes, dim3((nfaces + 255) / 256), dim3(256), 0, st, dP, dF, nfaces, tri[0]);
         GNode root{};
         root.first = 0; root.count = nfaces; root.depth = 0; root.left = root.right = -1;
-        const uint32_t init[2] = {1u, 0u};
+        const uint32_t init[3] = {1u, 0u, 0u};
+        uint32_t large_nodes = nfaces > 64u ? 1u : 0u;
         ING_HIP(hipMemcpyAsync(nodes, &root, sizeof root, hipMemcpyHostToDevice, st));
         ING_HIP(hipMemcpyAsync(scalars, init, sizeof init, hipMemcpyHostToDevice, st));
         uint32_t level_start = 0, level_end = 1;
@@ -311,12 +407,18 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
             // (the first levels hold few nodes with many triangles each: large workgroups there, small ones below)
             const uint32_t level_nodes = level_end - level_start;
             const uint32_t block = (uint64_t)level_nodes * 2048u <= nfaces ? 1024u : ((uint64_t)level_nodes * 512u <= nfaces ? 512u : 256u);
-            hipLaunchKernelGGL(k_build_level, dim3(level_nodes), dim3(block), 0, st, tri[from], tri[1 - from], nodes, level_start, node_cap,
-                               scalars, order, max_depth, scalars + 1);
+            // (the level's nodes of more than 64 triangles, counted when they were made: without any, no large-node launch)
+            if (large_nodes)
+                hipLaunchKernelGGL(k_build_level, dim3(level_nodes), dim3(block), 0, st, tri[from], tri[1 - from], nodes, level_start, node_cap,
+                                   scalars, order, max_depth, scalars + 1, 1u);
+            hipLaunchKernelGGL(k_build_level_small, dim3((level_nodes + 3u) / 4u), dim3(256), 0, st, tri[from], tri[1 - from], nodes, level_start, level_end,
+                               node_cap, scalars, order, max_depth, scalars + 1);
             ING_HIP(hipGetLastError());
-            uint32_t now[2];
+            uint32_t now[3];
             ING_HIP(hipMemcpyAsync(now, scalars, sizeof now, hipMemcpyDeviceToHost, st));
+            ING_HIP(hipMemsetAsync(scalars + 2, 0, sizeof(uint32_t), st));
             ING_HIP(hipStreamSynchronize(st));
+            large_nodes = now[2];
             if (now[1] & 1u) throw rtflat::Unsupported("bounding hierarchy deeper than the device walk stack");
             if (now[1] & 2u) throw HipFailure{"device hierarchy build ran out of node slots"};
             level_start = level_end; level_end = std::min(now[0], node_cap);
