@@ -117,7 +117,7 @@ struct BuildNode { V3 lo, hi; int left = -1, right = -1; uint32_t first = 0, cou
 // A mesh build that runs somewhere else (on the device, rt_ingest.hip): same inputs and outputs as the host's
 // build_bvh below, and the same tree, node for node.
 using MeshBuilder = std::function<void(const double* positions, uint32_t num_positions, const uint32_t* faces, uint32_t num_faces,
-                                       int max_depth, std::vector<BuildTri>& tris, std::vector<BuildNode>& nodes)>;
+                                       int max_depth, std::vector<uint32_t>& face_order, std::vector<BuildNode>& nodes)>;
 
 struct FlatScene {
     std::vector<DInstance> instances;
@@ -239,12 +239,13 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     const double* P = d.mesh_f64 + m.positions_off;
     const uint32_t* F = d.mesh_u32 + m.faces_off;
     auto pos = [&](uint32_t i) { if (i >= m.num_positions) throw Invalid("mesh face index out of range"); return V3{P[3 * i], P[3 * i + 1], P[3 * i + 2]}; };
-    std::vector<BuildTri> bt(m.num_faces);
+    std::vector<uint32_t> face_order;                            // the faces in the order the leaves hold them
     std::vector<BuildNode> bn(1);
     if (fs.mesh_builder) {
         for (uint32_t f = 0; f < 3 * m.num_faces; ++f) if (F[f] >= m.num_positions) throw Invalid("mesh face index out of range");
-        fs.mesh_builder(P, m.num_positions, F, m.num_faces, RT_BVH_STACK - 2, bt, bn);
+        fs.mesh_builder(P, m.num_positions, F, m.num_faces, RT_BVH_STACK - 2, face_order, bn);
     } else {
+        std::vector<BuildTri> bt(m.num_faces);
         for (uint32_t f = 0; f < m.num_faces; ++f) {
             V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
             bt[f].lo = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
@@ -254,6 +255,8 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
         }
         bn.reserve(2 * m.num_faces + 2);
         build_bvh(bt, bn, 0, 0, m.num_faces, 0, RT_BVH_STACK - 2);
+        face_order.resize(m.num_faces);
+        for (uint32_t i = 0; i < m.num_faces; ++i) face_order[i] = bt[i].face;
     }
     // pad boxes so that slab-test rounding can never cull a triangle lying on a box face
     V3 ext = bn[0].hi - bn[0].lo;
@@ -269,7 +272,7 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
     // triangles in BVH order; derived values as Mesh::from_path computes them (mesh.rs:396-404)
     fs.mesh_tris.reserve(fs.mesh_tris.size() + m.num_faces);
     for (uint32_t i = 0; i < m.num_faces; ++i) {
-        uint32_t f = bt[i].face;
+        uint32_t f = face_order[i];
         V3 a = pos(F[3 * f]), b = pos(F[3 * f + 1]), c = pos(F[3 * f + 2]);
         V3 cr = cross(b - a, c - b);
         DMeshTri t{};

@@ -114,12 +114,28 @@ uint32_t exclusive_scan(Pool& pool, uint32_t* data, uint32_t n, hipStream_t st) 
 }
 
 // ================================================================== bounding hierarchy
-struct GTri { double lo[3], hi[3], c[3]; uint32_t face, pad; };
+struct GTri { double lo[3], hi[3], c[3]; uint32_t face, pad; };   // a triangle's record, in registers
+// ... and in memory, component by component (component k of triangle i at f[k * n + i]): the lanes of a wave work on
+// neighbouring triangles, so every load and store covers whole cache lines.
+struct TriArray {
+    double* f; uint32_t* face; uint32_t n;
+    __device__ GTri load(uint32_t i) const {
+        GTri t;
+        for (int k = 0; k < 3; ++k) { t.lo[k] = f[(size_t)k * n + i]; t.hi[k] = f[(size_t)(3 + k) * n + i]; t.c[k] = f[(size_t)(6 + k) * n + i]; }
+        t.face = face[i]; t.pad = 0;
+        return t;
+    }
+    __device__ void store(uint32_t i, const GTri& t) const {
+        for (int k = 0; k < 3; ++k) { f[(size_t)k * n + i] = t.lo[k]; f[(size_t)(3 + k) * n + i] = t.hi[k]; f[(size_t)(6 + k) * n + i] = t.c[k]; }
+        face[i] = t.face;
+    }
+    __device__ double centre(uint32_t i, int axis) const { return f[(size_t)(6 + axis) * n + i]; }
+};
 struct GNode { double lo[3], hi[3]; uint32_t first, count; int left, right; uint32_t depth, pad; };
 constexpr int BINS = 16;                        // as the host builder (rt_flatten.hpp, build_bvh)
 constexpr uint32_t LEAF = 2;
 
-__global__ void __launch_bounds__(256) k_tri_boxes(const double* P, const uint32_t* F, uint32_t n, GTri* out) {
+__global__ void __launch_bounds__(256) k_tri_boxes(const double* P, const uint32_t* F, uint32_t n, TriArray out) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     GTri t;
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(256) k_tri_boxes(const double* P, const uint32
         t.c[k] = (t.lo[k] + t.hi[k]) * 0.5;
     }
     t.face = f; t.pad = 0;
-    out[f] = t;
+    out.store(f, t);
 }
 
 // doubles as unsigned keys with the same order (for integer min / max atomics in LDS)
@@ -189,7 +205,7 @@ __device__ inline void sweep_bins(const unsigned long long (*blo)[BINS][3], cons
 // per lane, no workgroup barriers.  Same steps, same arithmetic and same order as k_build_level, which leaves these
 // nodes alone when `small_apart` is set.
 __global__ void __launch_bounds__(256)
-k_build_level_small(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes, uint32_t level_start, uint32_t level_end, uint32_t node_cap,
+k_build_level_small(TriArray src, TriArray dst, GNode* nodes, uint32_t level_start, uint32_t level_end, uint32_t node_cap,
                     uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error) {
     __shared__ unsigned long long blo_all[4][3][BINS][3], bhi_all[4][3][BINS][3];
     __shared__ unsigned int bcount_all[4][3][BINS];
@@ -205,7 +221,7 @@ k_build_level_small(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode*
     const double inf = INFINITY;
     const bool mine = lane < count;
     GTri t{};
-    if (mine) t = src[first + lane];
+    if (mine) t = src.load(first + lane);
     double lo[3], hi[3], clo[3], chi[3];
     for (int k = 0; k < 3; ++k) {
         lo[k] = mine ? t.lo[k] : inf; hi[k] = mine ? t.hi[k] : -inf; clo[k] = mine ? t.c[k] : inf; chi[k] = mine ? t.c[k] : -inf;
@@ -245,12 +261,12 @@ k_build_level_small(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode*
     uint32_t mid;
     if (axis < 0) {
         mid = first + count / 2;
-        if (mine) dst[first + lane] = t;
+        if (mine) dst.store(first + lane, t);
     } else {
         const bool left = mine && min(BINS - 1, (int)((t.c[axis] - clo[axis]) * scale[axis])) <= bin;
         const unsigned long long ml = __ballot(left), mr = __ballot(mine && !left), lt = (1ull << lane) - 1ull;
         const uint32_t n_left = (uint32_t)__popcll(ml);
-        if (mine) dst[first + (left ? (uint32_t)__popcll(ml & lt) : n_left + (uint32_t)__popcll(mr & lt))] = t;
+        if (mine) dst.store(first + (left ? (uint32_t)__popcll(ml & lt) : n_left + (uint32_t)__popcll(mr & lt)), t);
         mid = first + n_left;
         if (mid == first || mid == first + count) mid = first + count / 2;
     }
@@ -271,7 +287,7 @@ k_build_level_small(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode*
 // `src`; a leaf writes their faces to `order` (its final place), an inner node writes them partitioned to `dst`
 // and appends its two children to `nodes`.
 __global__ void __launch_bounds__(1024)
-k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes, uint32_t level_start, uint32_t node_cap,
+k_build_level(TriArray src, TriArray dst, GNode* nodes, uint32_t level_start, uint32_t node_cap,
               uint32_t* node_count, uint32_t* order, int max_depth, uint32_t* error, uint32_t small_apart) {
     __shared__ double red[16];
     __shared__ unsigned long long blo[3][BINS][3], bhi[3][BINS][3];
@@ -285,7 +301,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
     const double inf = INFINITY;
     double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, clo[3] = {inf, inf, inf}, chi[3] = {-inf, -inf, -inf};
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const GTri& t = src[first + i];
+        const GTri t = src.load(first + i);
         for (int k = 0; k < 3; ++k) {
             lo[k] = fmin(lo[k], t.lo[k]); hi[k] = fmax(hi[k], t.hi[k]);
             clo[k] = fmin(clo[k], t.c[k]); chi[k] = fmax(chi[k], t.c[k]);
@@ -298,7 +314,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
     if (threadIdx.x == 0) for (int k = 0; k < 3; ++k) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
     if (count <= LEAF || (int)depth >= max_depth) {
         if (count > LEAF && count > 7u && threadIdx.x == 0) atomicOr(error, 1u);     // deeper than the walk's stack
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) order[first + i] = src[first + i].face;
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) order[first + i] = src.face[first + i];
         if (threadIdx.x == 0) { nd.left = -1; nd.right = -1; }
         return;
     }
@@ -311,12 +327,17 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
     double scale[3];
     for (int a = 0; a < 3; ++a) scale[a] = chi[a] > clo[a] ? (double)BINS / (chi[a] - clo[a]) : 0.0;
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const GTri& t = src[first + i];
+        const GTri t = src.load(first + i);
         for (int a = 0; a < 3; ++a) {
             if (!(chi[a] > clo[a])) continue;
             const int b = min(BINS - 1, (int)((t.c[a] - clo[a]) * scale[a]));
             atomicAdd(&bcount[a][b], 1u);
-            for (int k = 0; k < 3; ++k) { atomicMin(&blo[a][b][k], order_key(t.lo[k])); atomicMax(&bhi[a][b][k], order_key(t.hi[k])); }
+            // (a bin's bounds soon stop moving: a plain read first, the atomic only when it would change something)
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long kl = order_key(t.lo[k]), kh = order_key(t.hi[k]);
+                if (kl < blo[a][b][k]) atomicMin(&blo[a][b][k], kl);
+                if (kh > bhi[a][b][k]) atomicMax(&bhi[a][b][k], kh);
+            }
         }
     }
     __syncthreads();
@@ -330,12 +351,12 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
     uint32_t mid;
     if (axis < 0) {                   // all centroids coincide: split in the middle
         mid = first + count / 2;
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[first + i] = src[first + i];
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst.store(first + i, src.load(first + i));
     } else {
         const double a0 = clo[axis], k = scale[axis];
         uint32_t mine = 0;
         for (uint32_t i = threadIdx.x; i < count; i += blockDim.x)
-            if (min(BINS - 1, (int)((src[first + i].c[axis] - a0) * k)) <= bin) ++mine;
+            if (min(BINS - 1, (int)((src.centre(first + i, axis) - a0) * k)) <= bin) ++mine;
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
         if ((threadIdx.x & 63u) == 0) atomicAdd(&s_left, mine);
         __syncthreads();
@@ -349,7 +370,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
             const bool valid = i < count;
             GTri t;
             bool left = false;
-            if (valid) { t = src[first + i]; left = min(BINS - 1, (int)((t.c[axis] - a0) * k)) <= bin; }
+            if (valid) { t = src.load(first + i); left = min(BINS - 1, (int)((t.c[axis] - a0) * k)) <= bin; }
             const unsigned long long ml = __ballot(valid && left), mr = __ballot(valid && !left);
             if (lane == 0) { wl[wave] = (unsigned int)__popcll(ml); wr[wave] = (unsigned int)__popcll(mr); }
             __syncthreads();
@@ -357,7 +378,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
             for (uint32_t w = 0; w < nwaves; ++w) { if (w < wave) { bl += wl[w]; br += wr[w]; } tl += wl[w]; tr += wr[w]; }
             if (valid) {
                 const uint32_t at = left ? run_left + bl + (uint32_t)__popcll(ml & lt) : n_left + run_right + br + (uint32_t)__popcll(mr & lt);
-                dst[first + at] = t;
+                dst.store(first + at, t);
             }
             run_left += tl; run_right += tr;
             __syncthreads();
@@ -379,7 +400,7 @@ k_build_level(const GTri* __restrict__ src, GTri* __restrict__ dst, GNode* nodes
 }
 
 void device_build(int device, const double* P, uint32_t npos, const uint32_t* F, uint32_t nfaces, int max_depth,
-                  std::vector<rtflat::BuildTri>& bt, std::vector<rtflat::BuildNode>& bn) {
+                  std::vector<uint32_t>& face_order, std::vector<rtflat::BuildNode>& bn) {
     const auto t_begin = std::chrono::steady_clock::now();
     try {
         ING_HIP(hipSetDevice(device));
@@ -389,7 +410,8 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
         uint32_t* dF = pool.get<uint32_t>(3 * (size_t)nfaces);
         ING_HIP(hipMemcpyAsync(dP, P, 3 * (size_t)npos * sizeof(double), hipMemcpyHostToDevice, st));
         ING_HIP(hipMemcpyAsync(dF, F, 3 * (size_t)nfaces * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        GTri* tri[2] = {pool.get<GTri>(nfaces), pool.get<GTri>(nfaces)};
+        TriArray tri[2];
+        for (TriArray& t : tri) { t.f = pool.get<double>(9 * (size_t)nfaces); t.face = pool.get<uint32_t>(nfaces); t.n = nfaces; }
         const uint32_t node_cap = 2 * nfaces + 2;
         GNode* nodes = pool.get<GNode>(node_cap);
         uint32_t* order = pool.get<uint32_t>(nfaces);
@@ -426,13 +448,11 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
         }
         const auto t_levels = std::chrono::steady_clock::now();
         std::vector<GNode> g(level_end);
-        std::vector<uint32_t> ord(nfaces);
+        face_order.resize(nfaces);
         ING_HIP(hipMemcpy(g.data(), nodes, g.size() * sizeof(GNode), hipMemcpyDeviceToHost));
-        ING_HIP(hipMemcpy(ord.data(), order, ord.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ING_HIP(hipMemcpy(face_order.data(), order, face_order.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const auto t_copied = std::chrono::steady_clock::now();
         // nodes renumbered in the order the host builder's recursion creates them (children allocated before descending)
-        bt.assign(nfaces, rtflat::BuildTri{});
-        for (uint32_t i = 0; i < nfaces; ++i) bt[i].face = ord[i];
         // (the recursion "allocate both children, descend left, descend right" with a stack of its own: the right child waits on it)
         bn.assign(g.size(), rtflat::BuildNode{});
         std::vector<std::pair<int, uint32_t>> todo;              // (index in bn, index in g)
@@ -852,7 +872,7 @@ int obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out) {
 // ---- used by rt_api.hip
 rtflat::MeshBuilder rt_device_mesh_builder(int device) {
     return [device](const double* P, uint32_t npos, const uint32_t* F, uint32_t nfaces, int max_depth,
-                    std::vector<rtflat::BuildTri>& bt, std::vector<rtflat::BuildNode>& bn) { device_build(device, P, npos, F, nfaces, max_depth, bt, bn); };
+                    std::vector<uint32_t>& face_order, std::vector<rtflat::BuildNode>& bn) { device_build(device, P, npos, F, nfaces, max_depth, face_order, bn); };
 }
 // Flips the rows of an uploaded image in place (texels: device memory).
 hipError_t rt_device_flip_rows(uint8_t* texels, uint32_t row_bytes, uint32_t height, hipStream_t stream) {
