@@ -33,8 +33,22 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def _deps(depfile):
+    """prerequisites listed in a compiler-written dependency file (make syntax), or None when it is missing"""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    deps = []
+    for part in text.split(":", 1)[-1].split():
+        deps.append(part)
+    return deps
+
+
 def build_hip(force=False, jobs=None):
-    """every csrc/*.hip and csrc/variants/*.hip compile to objects side by side (csrc/obj/), then link."""
+    """every csrc/*.hip and csrc/variants/*.hip compile to objects side by side (csrc/obj/), then link.
+    An object is rebuilt when its source or any header it included last time (csrc/obj/*.d) is newer."""
     from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(HERE, "csrc")
     obj_dir = os.path.join(src_dir, "obj")
@@ -47,10 +61,14 @@ def build_hip(force=False, jobs=None):
     flags = [f for f in HIP_FLAGS if f != "-shared"]
     todo, objects = [], []
     for src in sources:
-        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        stem = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(obj_dir, stem + ".o")
+        dep = os.path.join(obj_dir, stem + ".d")
         objects.append(obj)
-        if force or _newer(obj, headers + [src]):
-            todo.append(["hipcc", *flags, "-c", "-I" + INCLUDE, "-o", obj, src])
+        known = _deps(dep)
+        mine = [h for h in known if os.path.exists(h) and not h.startswith("/opt/")] if known is not None else headers
+        if force or _newer(obj, mine + [src]):
+            todo.append(["hipcc", *flags, "-c", "-MD", "-MF", dep, "-I" + INCLUDE, "-o", obj, src])
     if todo:
         jobs = jobs or min(len(todo), max(1, min(16, os.cpu_count() or 1)))
         with ThreadPoolExecutor(max_workers=jobs) as pool:

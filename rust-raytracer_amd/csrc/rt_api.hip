@@ -134,6 +134,9 @@ struct RtScene {
     DeviceBuf wf_sticky;
     unsigned int* h_dropped = nullptr;
     unsigned int dropped_seen = 0, dropped_reported = 0;
+    // Shade kernel of the queue pipeline per hit list (materials without / with rays): 0 the general kernel, 1 / 2 the
+    // kernel built for a class of simple materials (k_wf_shade in rt_wavefront.h), when every material on the list is of it
+    int shade_cls[2] = {0, 0};
     uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
     bool last_used_queues = false, queue_overflowed = false;
     int last_attempts = 1;                 // frames the most recent synchronous call enqueued
@@ -254,6 +257,13 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
     d.features = fs.features; d.max_ray_spawn = fs.max_ray_spawn; d.max_shadow_spawn = fs.max_shadow_spawn;
     d.inline_point_lights = fs.inline_point_lights;
+    {   // (RT_WF_SHADE_CLS=0: every list on the general kernel, for tests that compare the two)
+        const char* e = std::getenv("RT_WF_SHADE_CLS");
+        const bool allow = !(e && std::atoi(e) == 0);
+        const uint32_t glass = (1u << DS_REFLECTION) | (1u << DS_TRANSLUCENT) | (1u << DS_COMPOSITE);
+        if (allow && fs.shade_kinds[0] == (1u << DS_PHONG) && fs.shade_depth[0] == 0) s->shade_cls[0] = 1;
+        if (allow && fs.shade_kinds[1] != 0 && (fs.shade_kinds[1] & ~glass) == 0 && fs.shade_depth[1] <= 1) s->shade_cls[1] = 2;
+    }
     {   // LDS-resident BVH when every mesh fits beside nothing else in one CU's LDS
         while (fs.lds_blob.size() % 16) fs.lds_blob.push_back(0);
         int lds_max = 0;
@@ -655,8 +665,18 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                 }
                 lrc = wf_launch(2, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
-                lrc = wf_launch(1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
-                if (lrc != RT_OK) return lrc;
+                if (s->shade_cls[0] == 0 && s->shade_cls[1] == 0) {       // both hit lists on the general kernel, in one launch
+                    wa.shade_lists = 3u;
+                    lrc = wf_launch(1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    if (lrc != RT_OK) return lrc;
+                } else {                                                 // a launch per list, each on the kernel for its materials
+                    wa.shade_lists = 2u;
+                    lrc = wf_launch(s->shade_cls[1] ? 3 + s->shade_cls[1] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    if (lrc != RT_OK) return lrc;
+                    wa.shade_lists = 1u;
+                    lrc = wf_launch(s->shade_cls[0] ? 3 + s->shade_cls[0] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    if (lrc != RT_OK) return lrc;
+                }
             }
         }
         wa.walk_overflow = overflow0;

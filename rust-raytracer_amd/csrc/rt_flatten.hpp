@@ -153,6 +153,10 @@ struct FlatScene {
     DAffine background_w2l{};
     uint32_t max_mesh_bvh_bytes = 0;
     uint32_t features = 0, max_ray_spawn = 0, max_shadow_spawn = 0, inline_point_lights = 0;
+    // What the materials in use contain, apart for those that spawn no rays ([0]) and those that do ([1]): bit k of
+    // shade_kinds is set when a shader of DShaderKind k occurs in one of them, shade_depth is their deepest
+    // nesting of group shaders (0: no groups).  The queue pipeline picks its shade kernels by these.
+    uint32_t shade_kinds[2] = {0, 0}, shade_depth[2] = {0, 0};
     MeshBuilder mesh_builder;        // empty: the host builds the meshes' hierarchies
     bool flip_on_device = false;     // images are staged top row first and flipped once they are in device memory
     std::vector<uint8_t> lds_blob;   // LBvhNode + LMeshTri arrays of all meshes
@@ -446,6 +450,15 @@ private:
         if (s.kind == RT_SHADER_CHAIN) return count_phongs(d_.shader_child_idx[s.first_child + s.num_children - 1]);
         return 0;
     }
+    // Shader kinds below shader i (collected in `kinds`, one bit per DShaderKind) and the nesting depth of its groups.
+    uint32_t material_shape(uint32_t i, uint32_t& kinds) {
+        const DShader& s = fs_.shaders[i];
+        kinds |= 1u << s.kind;
+        if (s.kind != DS_MIX && s.kind != DS_COMPOSITE && s.kind != DS_CHAIN) return 0;
+        uint32_t deepest = 0;
+        for (uint32_t k = 0; k < s.num_children; ++k) deepest = std::max(deepest, material_shape(fs_.shader_child_idx[s.first_child + k], kinds));
+        return deepest + 1;
+    }
     void analyse() {
         uint32_t f = 0;
         for (const DPrim& p : fs_.prims) {
@@ -482,6 +495,10 @@ private:
             uint32_t r = std::min<uint32_t>(count_spawns(i), RT_SHADE_MAX_SPAWN);
             uint32_t sh = inline_points ? 0u : std::min<uint32_t>(count_phongs(i) * point_lights_, RT_SHADE_MAX_SPAWN);
             fs_.shader_bounds[i] = r | (sh << 16);
+        }
+        for (const DInstance& in : fs_.instances) {
+            const int cls = (fs_.shader_bounds[in.shader] & 0xFFFFu) ? 1 : 0;
+            fs_.shade_depth[cls] = std::max(fs_.shade_depth[cls], material_shape(in.shader, fs_.shade_kinds[cls]));
         }
         fs_.features = f; fs_.max_ray_spawn = max_r; fs_.max_shadow_spawn = max_s; fs_.inline_point_lights = inline_points ? 1 : 0;
     }

@@ -483,7 +483,13 @@ RT_DEV d3 phong_color(const DScene& sc, const DShader& sh, d3 p, d3 n, d3 ray_di
                     phong_lit(c, surface_dot, light_direction, intensity);
                 }
             } else if (sink.room()) {
-                PhongCtx one = c;
+                // (the material's constants are read again for every light, through a pointer the compiler cannot see
+                // through: kept in registers across the loop they cost the shade kernels their third wave per SIMD)
+                const double* mat = sh.p;
+                asm volatile("" : "+v"(mat));
+                PhongCtx one;
+                one.p = p; one.n = n; one.view = c.view;
+                one.diffuse = ld3(mat); one.specular = ld3(mat + 3); one.shininess = mat[9];
                 one.total = mk3(0.0, 0.0, 0.0);
                 phong_lit(one, surface_dot, light_direction, intensity);
                 sink.shadow(p, light_direction, light_distance, win * one.total);
@@ -531,9 +537,16 @@ RT_DEV void fresnel(d3 d, d3 n, double ior, double& kt, double& kr) {           
 // ------------------------------------------------------------------ shader-tree interpreter
 // Walks the material of a hit depth-first, left to right — the order in which the
 // reference's nested get_color calls run — and returns L; spawned rays go to `spawn`.
-template <uint32_t F, bool COUNT, class SINK>
+// KINDS / DEPTH narrow the interpreter to what the materials it will meet can contain (bit k of KINDS:
+// shader kind k may occur; DEPTH: deepest nesting of group shaders): a kernel that only shades glass
+// (Composite of Reflection and Translucent) carries neither the Phong code nor its registers, one
+// that shades at most one level of grouping no frame array in scratch memory.  The caller guarantees
+// the bounds (the host derives them from the scene's materials); a shader outside them yields black.
+#define RT_SHADER_KINDS_ALL 0xFFu
+template <uint32_t F, bool COUNT, class SINK, uint32_t KINDS = RT_SHADER_KINDS_ALL, int DEPTH = RT_SHADE_MAX_FRAMES>
 RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit, d3 ray_dir, d3 ray_contrib,
                     uint64_t stream, uint32_t path, SINK& sink, Work<COUNT>& wk) {
+    constexpr auto has = [](uint32_t kind) { return (KINDS >> kind) & 1u; };
     struct Frame {
         uint32_t shader, cursor, spawn_begin, child_spawn_begin;
         d3 acc;          // MIX: running product; COMPOSITE: running sum (local parts)
@@ -545,7 +558,7 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
     // Materials with one level of grouping never touch `below`, whose dynamic indexing puts it into
     // scratch memory: a scratch read has to wait for the queue stores issued before it.
     Frame top;
-    Frame below[RT_SHADE_MAX_FRAMES - 1];
+    Frame below[DEPTH > 1 ? DEPTH - 1 : 1];
     int depth = 0;
     d3 n = hit.n;
     uint32_t cur = root_shader;
@@ -557,20 +570,24 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         const DShader& sh = sc.shaders[cur];
         bool returned = true;
         switch (sh.kind) {
-            case DS_PHONG: value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, win, stream, path, sink, wk); break;
+            case DS_PHONG:
+                if constexpr (has(DS_PHONG)) value = phong_color<F, COUNT>(sc, sh, hit.p, n, ray_dir, win, stream, path, sink, wk); else value = mk3(0.0, 0.0, 0.0);
+                break;
             case DS_TEXTURE:                                                                  // shader/texture.rs:16-19
-                if constexpr (F & RTF_IMAGES) value = texture_color(sc, sh.ref, hit.u, hit.v); else value = mk3(0.0, 0.0, 0.0);
+                if constexpr ((F & RTF_IMAGES) && has(DS_TEXTURE)) value = texture_color(sc, sh.ref, hit.u, hit.v); else value = mk3(0.0, 0.0, 0.0);
                 break;
             case DS_NORMAL_MAP:                                                               // shader.rs:170-173
-                if constexpr (F & RTF_IMAGES) value = perturbed_normal(sc, sc.normal_maps[sh.ref], hit.u, hit.v, n, hit.tangent); else value = mk3(0.0, 0.0, 0.0);
+                if constexpr ((F & RTF_IMAGES) && has(DS_NORMAL_MAP)) value = perturbed_normal(sc, sc.normal_maps[sh.ref], hit.u, hit.v, n, hit.tangent); else value = mk3(0.0, 0.0, 0.0);
                 break;
             case DS_REFLECTION: {                                                             // shader/reflection.rs:14-18
-                d3 k = ld3(sh.p);
-                if (sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), win * k, cin * k, cur * 4 + 0);
                 value = mk3(0.0, 0.0, 0.0);
+                if constexpr (has(DS_REFLECTION)) {
+                    d3 k = ld3(sh.p);
+                    if (sink.room()) sink.ray(hit.p, reflect_dir(ray_dir, n), win * k, cin * k, cur * 4 + 0);
+                }
                 break;
             }
-            case DS_TRANSLUCENT: {                                                            // shader/translucent.rs:50-62
+            case DS_TRANSLUCENT: if constexpr (!has(DS_TRANSLUCENT)) { value = mk3(0.0, 0.0, 0.0); break; } else {   // shader/translucent.rs:50-62
                 if (sh.p[4] != 0.0) {
                     // the shader's earlier revision (kept as a comment at translucent.rs:59): the colour of the
                     // transmitted ray alone, unscaled, its contribution scaled by `translucency`
@@ -585,17 +602,17 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
                 value = mk3(0.0, 0.0, 0.0);
                 break;
             }
-            default: {   // group shaders open a frame and descend into their first child
-                if (depth >= RT_SHADE_MAX_FRAMES || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
-                if (depth > 0) below[depth - 1] = top;
+            default: if constexpr (DEPTH == 0) { value = mk3(0.0, 0.0, 0.0); break; } else {   // group shaders open a frame and descend into their first child
+                if (depth >= DEPTH || sh.num_children == 0) { value = mk3(0.0, 0.0, 0.0); break; }
+                if constexpr (DEPTH > 1) { if (depth > 0) below[depth - 1] = top; }
                 depth++;
                 Frame& f = top;
                 f.shader = cur; f.cursor = 0; f.spawn_begin = sink.mark(); f.child_spawn_begin = f.spawn_begin; f.cin = cin; f.win = win; f.saved_n = n;
-                if (sh.kind == DS_MIX) {                                                      // shader.rs:66-69
+                if (has(DS_MIX) && sh.kind == DS_MIX) {                                       // shader.rs:66-69
                     f.acc = mk3(1.0, 1.0, 1.0);
                     cur = sc.shader_child_idx[sh.first_child];
                     cin = f.cin * f.acc; win = f.win * f.acc;
-                } else if (sh.kind == DS_COMPOSITE) {                                         // shader.rs:95-102
+                } else if (!has(DS_CHAIN) || sh.kind == DS_COMPOSITE) {                       // shader.rs:95-102
                     f.acc = mk3(0.0, 0.0, 0.0);
                     cur = sc.shader_child_idx[sh.first_child];
                     cin = f.cin * sc.shader_child_weight[sh.first_child]; win = f.win * sc.shader_child_weight[sh.first_child];
@@ -616,31 +633,32 @@ RT_DEV d3 shade_hit(const DScene& sc, uint32_t root_shader, const WorldHit& hit,
         if (!returned) continue;
         // ---- `value` (+ spawns since child_spawn_begin) returns to the enclosing frames
         for (;;) {
-            if (depth == 0) return value;
+            if (DEPTH == 0 || depth == 0) return value;
             Frame& f = top;
             const DShader& g = sc.shaders[f.shader];
-            if (g.kind == DS_MIX) {
+            if (has(DS_MIX) && g.kind == DS_MIX) {
                 // acc' = acc * (value + rays_child): earlier rays scale by value, the child's by acc (they were, through win)
                 sink.scale(f.spawn_begin, f.child_spawn_begin, value);
                 f.acc = f.acc * value;
-            } else if (g.kind == DS_COMPOSITE) {
+            } else if (!has(DS_CHAIN) || g.kind == DS_COMPOSITE) {
                 double w = sc.shader_child_weight[g.first_child + f.cursor];   // (the child's rays carry w already, through win)
                 f.acc = f.acc + w * value;
             } else {
                 f.acc = value;
             }
             f.cursor++;
-            if (g.kind != DS_CHAIN && f.cursor < g.num_children) {   // next sibling
+            if ((!has(DS_CHAIN) || g.kind != DS_CHAIN) && f.cursor < g.num_children) {   // next sibling
                 f.child_spawn_begin = sink.mark();
                 cur = sc.shader_child_idx[g.first_child + f.cursor];
-                cin = g.kind == DS_MIX ? f.cin * f.acc : f.cin * sc.shader_child_weight[g.first_child + f.cursor];
-                win = g.kind == DS_MIX ? f.win * f.acc : f.win * sc.shader_child_weight[g.first_child + f.cursor];
+                const bool mix = has(DS_MIX) && g.kind == DS_MIX;
+                cin = mix ? f.cin * f.acc : f.cin * sc.shader_child_weight[g.first_child + f.cursor];
+                win = mix ? f.win * f.acc : f.win * sc.shader_child_weight[g.first_child + f.cursor];
                 break;
             }
             value = f.acc;                                           // group finished
-            n = f.saved_n;
+            if constexpr (has(DS_CHAIN)) n = f.saved_n;
             depth--;
-            if (depth > 0) top = below[depth - 1];
+            if constexpr (DEPTH > 1) { if (depth > 0) top = below[depth - 1]; }
         }
     }
 }

@@ -6,7 +6,14 @@
 // variant lives in a source file of its own under variants/ (they compile side by side); the frame
 // driver in rt_api.hip only sees the launch functions declared here.
 #pragma once
+// (the translation units of the persistent trace kernel define RT_VARIANT_TRACE_ONLY: they do not depend on
+// the queue pipeline's header, and are not rebuilt when it changes)
+#ifdef RT_VARIANT_TRACE_ONLY
+#include "rt_kernels.h"
+struct WfArgs;
+#else
 #include "rt_wavefront.h"
+#endif
 
 constexpr uint32_t V_MESH = RTF_MESH;                                         // rooms + meshes, point lights (glass_monkey)
 constexpr uint32_t V_AREA = RTF_FACED | RTF_INLINE_LIGHTS | RTF_IMAGES;       // square light, cube, textures (light_room)
@@ -32,7 +39,8 @@ struct LaunchStatus {             // hipSuccess, or the failing call
     LaunchStatus rt_launch_trace_##name(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta);
 RT_TRACE_VARIANTS(RT_DECLARE_TRACE)
 #undef RT_DECLARE_TRACE
-// which: 0 analytic, 1 shade, 2 settle, 3 analytic redo (scenes with composite shapes)
+// which: 0 analytic, 1 shade, 2 settle, 3 analytic redo (scenes with composite shapes), 4 / 5 shade on the kernel for
+// material class 1 / 2 (k_wf_shade; only built for scenes whose tables fit LDS, else the general kernel runs)
 #define RT_DECLARE_WF(name, F) \
     LaunchStatus rt_launch_wf_##name(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa);
 RT_WF_VARIANTS(RT_DECLARE_WF)
@@ -67,12 +75,13 @@ LaunchStatus launch_trace_variant(bool count, uint32_t grid, hipStream_t stream,
     return {hipGetLastError(), "k_trace launch"};
 }
 
+#ifndef RT_VARIANT_TRACE_ONLY
 template <uint32_t F>
 LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa) {
     const bool hot = ds.hot_bytes > 0;                                 // the scene's small tables fit into LDS
     const uint32_t tables = hot ? (ds.hot_bytes + 15u) & ~15u : 0u;
     uint32_t lds = tables;
-    if (which == 1) lds = tables + 4u * 640u * 8u;                     // + accumulation staging of the four waves
+    if (which == 1 || which == 4 || which == 5) lds = tables + 4u * 640u * 8u;   // + accumulation staging of the four waves
     if (which == 0 && ds.has_background) lds = tables + 4u * 640u * 8u + 4u * 128u * 4u;   // + staging and the waves' lists of rays that only see the sky box
     if (which == 2) lds = 4u * 640u * 8u + 4u * 128u * 4u;            // staging + the waves' lists of rays that left the scene
     const void* fn = nullptr;
@@ -80,10 +89,14 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
                              : (count ? (const void*)k_wf_analytic<F, true, false, false> : (const void*)k_wf_analytic<F, false, false, false>);
     else if (which == 1) fn = hot ? (count ? (const void*)k_wf_shade<F, true, true> : (const void*)k_wf_shade<F, false, true>)
                                   : (count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>);
+    else if (which == 4 && hot) fn = count ? (const void*)k_wf_shade<F, true, true, 1> : (const void*)k_wf_shade<F, false, true, 1>;
+    else if (which == 5 && hot) fn = count ? (const void*)k_wf_shade<F, true, true, 2> : (const void*)k_wf_shade<F, false, true, 2>;
+    else if (which == 4 || which == 5) fn = count ? (const void*)k_wf_shade<F, true, false> : (const void*)k_wf_shade<F, false, false>;
     else if (which == 2) fn = count ? (const void*)k_wf_settle<F, true> : (const void*)k_wf_settle<F, false>;
     else if constexpr ((F & RTF_CSG) != 0) {                            // 3: the analytic kernel's second run (composite shapes only)
-        fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, true> : (const void*)k_wf_analytic<F, false, true, true>)
-                 : (count ? (const void*)k_wf_analytic<F, true, false, true> : (const void*)k_wf_analytic<F, false, false, true>);
+        if (which == 3)
+            fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, true> : (const void*)k_wf_analytic<F, false, true, true>)
+                     : (count ? (const void*)k_wf_analytic<F, true, false, true> : (const void*)k_wf_analytic<F, false, false, true>);
     }
     if (!fn) return {hipErrorInvalidValue, "queue-pipeline kernel selection"};
     if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -91,3 +104,4 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);
     return {hipGetLastError(), "queue-pipeline kernel launch"};
 }
+#endif  // RT_VARIANT_TRACE_ONLY

@@ -117,6 +117,7 @@ struct WfArgs {
     const unsigned int* aa_count;
     uint32_t mode;
     uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
+    uint32_t shade_lists;             // k_wf_shade: the hit lists this launch works on (bit 0: materials without rays, bit 1: the others)
     uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
 };
 
@@ -868,12 +869,27 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
 // as holes (ray flags bit 3 / shadow slot RT_NO_SLOT).  The hit's own colour term goes to the
 // accumulators at once.
 // LDS: [small scene tables][per wave 64 x 10 words of staging]
-template <uint32_t F, bool COUNT, bool HOT>
-__global__ void __launch_bounds__(256)
+//
+// CLS picks the code for a class of materials; a.shade_lists the hit lists a launch works on (bit 0: materials
+// without rays, bit 1: the others).  The general kernel (CLS 0) carries the whole shader interpreter and
+// holds 229 registers, two waves per SIMD; most of its time it waits for memory.  When all materials of a
+// list are of a simple shape the host launches that list on a kernel built for the shape, which fits three
+// waves per SIMD without spilling:
+//   CLS 1  every material is a plain PhongShader (the walls of a room): no interpreter, no counting run
+//   CLS 2  Reflection / Translucent, alone or in one Composite (mirrors, glass): no Phong code, no frame array
+#define RT_SHADE_CLS_KINDS(CLS) ((CLS) == 1 ? (1u << DS_PHONG) : (CLS) == 2 ? ((1u << DS_REFLECTION) | (1u << DS_TRANSLUCENT) | (1u << DS_COMPOSITE)) : RT_SHADER_KINDS_ALL)
+#define RT_SHADE_CLS_DEPTH(CLS) ((CLS) == 1 ? 0 : (CLS) == 2 ? 1 : RT_SHADE_MAX_FRAMES)
+// (three waves per SIMD are asked for where they are known to fit without spills: the variants without feature bits beyond meshes)
+#define RT_SHADE_WAVES(F, CLS) (((CLS) != 0 && ((F) & ~RTF_MESH) == 0u) ? 3 : 2)
+template <uint32_t F, bool COUNT, bool HOT, int CLS = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES(F, CLS))))
 k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
+    constexpr uint32_t KINDS = RT_SHADE_CLS_KINDS(CLS);
+    constexpr int DEPTH = RT_SHADE_CLS_DEPTH(CLS);
     const uint32_t sq = a.sq_base + blockIdx.x % a.sq_count;
     const uint32_t cap = a.cap;
-    const uint32_t n1 = min(a.hit_count[2 * sq], a.sub), n2 = min(a.hit_count[2 * sq + 1], a.sub - n1);
+    const uint32_t listed1 = min(a.hit_count[2 * sq], a.sub);
+    const uint32_t n1 = (a.shade_lists & 1u) ? listed1 : 0u, n2 = (a.shade_lists & 2u) ? min(a.hit_count[2 * sq + 1], a.sub - listed1) : 0u;
     const uint32_t r1 = (n1 + 63u) & ~63u;                            // the second kind starts in a wave of its own
     const uint32_t rounded = (r1 + n2 + 63u) & ~63u;
     if ((blockIdx.x / a.sq_count) * blockDim.x >= rounded) return;      // nothing for this workgroup: leave before the tables are copied
@@ -911,11 +927,11 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
         RT_PROF_CYC(wk, PF_B_ITERS, t_prof);                              // the ray, the hit in world space
         // A material that spawns rays is run twice: first only to count what it will append (how
         // many rays depends on the hit: total reflection, contributions below the threshold), ...
-        if (shade && want_rays && !(a.debug & 3u)) {
+        if (CLS != 1 && shade && want_rays && !(a.debug & 3u)) {
             CountSink cs;
             cs.nrays = 0; cs.nshadows = 0; cs.depth = rdepth - 1; cs.drop_dead = sc.has_background == 0;
             Work<false> nowk = {};
-            (void)shade_hit<F, false>(sc, sc.instances[inst].shader, wh, rd, rc, 0ull, rpath, cs, nowk);
+            (void)shade_hit<F, false, CountSink, KINDS, DEPTH>(sc, sc.instances[inst].shader, wh, rd, rc, 0ull, rpath, cs, nowk);
             want_rays = min(want_rays, cs.nrays); want_shadows = min(want_shadows, cs.nshadows);
         }
         // ... then, with exactly that much room reserved in the next generation, for real
@@ -935,7 +951,11 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             sink.max_rays = want_rays; sink.max_shadows = want_shadows; sink.nrays = 0; sink.nshadows = 0;
             sink.parent_w = rw; sink.depth = rdepth - 1; sink.parent_path = rpath; sink.slot = rslot; sink.drop_dead = sc.has_background == 0; sink.dry = (a.debug & 4u) != 0;
             d3 local = wh.p;
-            if (!(a.debug & 3u)) local = shade_hit<F, COUNT>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
+            if (!(a.debug & 3u)) {
+                // (a plain Phong material is what the interpreter would call for it at once, with weight 1)
+                if constexpr (CLS == 1) local = phong_color<F, COUNT>(sc, sc.shaders[in.shader], wh.p, wh.n, rd, mk3(1.0, 1.0, 1.0), 0ull, rpath, sink, wk);
+                else local = shade_hit<F, COUNT, QueueSink, KINDS, DEPTH>(sc, in.shader, wh, rd, rc, 0ull, rpath, sink, wk);
+            }
             cslot = rslot;
             cval = rw * local;
             RT_PROF_CYC(wk, PF_B_LANES, t_prof);                          // material
