@@ -67,6 +67,9 @@ struct DeviceBuf {
 // once per device, with that device current, when the first scene is created on it.
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[64] = {};
+// ... and one event per device, recorded behind every frame that used the array: the next such frame waits for it,
+// so that frames of different scenes or streams take turns on the array instead of racing.
+hipEvent_t g_scratch_free[64] = {};
 int scratch_lookup(int device) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (device < 0 || device >= 64) return fail(RT_ERR_INVALID_ARG, "device index out of range");
@@ -74,6 +77,7 @@ int scratch_lookup(int device) {
     void* ptr = nullptr;
     HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned no address");
+    HIP_TRY(hipEventCreateWithFlags(&g_scratch_free[device], hipEventDisableTiming));
     g_scratch_ptr[device] = ptr;
     return RT_OK;
 }
@@ -108,8 +112,6 @@ struct Workspace {
     DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars;
     uint32_t wf_cap = 0;
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
-    std::vector<uint32_t> rows_host;
-    uint32_t rows_key[5] = {0, 0, 0, 0, 0};
     std::vector<DeviceBuf*> all() {
         return {&color, &distance, &hit_id, &mask, &list, &samples, &rows, &scalars, &rgb_full, &queue[0], &queue[1], &acc, &acc_flags, &lane_mem,
                 &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars};
@@ -203,6 +205,10 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
         rtflat::flatten(*desc, fs);
     } catch (const rtflat::Unsupported& e) {
         return fail(RT_ERR_UNSUPPORTED, e.what());
+    } catch (const rtflat::DeviceFailure& e) {
+        return fail(RT_ERR_DEVICE, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_DEVICE, "rt_scene_create: out of host memory");
     } catch (const std::exception& e) {
         return fail(RT_ERR_INVALID_ARG, e.what());
     }
@@ -240,7 +246,7 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     d.hot_bytes = hot.size() <= RT_HOT_LIMIT ? (uint32_t)hot.size() : 0u;
 #define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
     UP(tlas_nodes, fs.tlas_nodes); UP(tlas_index, fs.tlas_index); UP(tlas_unbounded, fs.tlas_unbounded);
-    UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_normals, fs.mesh_normals); UP(mesh_uvs, fs.mesh_uvs); UP(texels, fs.texels);
+    UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_attrs, fs.mesh_attrs); UP(texels, fs.texels);
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
     if (fs.flip_on_device)
@@ -443,25 +449,17 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     rp.recursion_depth = rc.recursion_depth; rp.aa_rays = rc.aa_rays; rp.aa_threshold = rc.aa_threshold; rp.seed = rc.seed;
     rp.rank = rc.rank; rp.nranks = rc.nranks ? rc.nranks : 1; rp.tile_rows = rc.tile_rows ? rc.tile_rows : 16;
 
-    // rows this rank renders: owned row blocks plus the AA halo
-    uint32_t key[5] = {W, H, rp.rank, rp.nranks, rp.tile_rows * 2 + (rc.anti_alias ? 1u : 0u)};
-    if (std::memcmp(key, w.rows_key, sizeof key) != 0 || w.rows_host.empty() || !w.rows.p) {
-        std::vector<uint8_t> need(H, 0);
-        for (uint32_t y = 0; y < H; ++y) {
-            bool mine = rp.nranks <= 1 || (y / rp.tile_rows) % rp.nranks == rp.rank;
-            if (!mine) continue;
-            need[y] = 1;
-            if (rc.anti_alias && rp.nranks > 1) { if (y > 0) need[y - 1] = 1; if (y + 1 < H) need[y + 1] = 1; }
-        }
-        w.rows_host.clear();
-        for (uint32_t y = 0; y < H; ++y) if (need[y]) w.rows_host.push_back(y);
-        int e = w.rows.ensure(std::max<size_t>(1, w.rows_host.size()) * sizeof(uint32_t));
-        if (e != RT_OK) return e;
-        if (!w.rows_host.empty()) HIP_TRY(hipMemcpyAsync(w.rows.p, w.rows_host.data(), w.rows_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));   // rows_host may be rewritten by the next call
-        std::memcpy(w.rows_key, key, sizeof key);
+    // rows this rank renders: owned row blocks plus the AA halo.  The list is written by the device (k_frame_rows);
+    // the host only counts them, so a frame needs neither an upload nor a synchronisation.
+    const bool halo = rc.anti_alias != 0;
+    uint32_t num_rows = 0;
+    for (uint32_t y = 0; y < H; ++y) if (rt_rank_renders_row(y, H, rp.rank, rp.nranks, rp.tile_rows, halo)) ++num_rows;
+    {
+        int re = w.rows.ensure(std::max<size_t>(1, num_rows) * sizeof(uint32_t));
+        if (re != RT_OK) return re;
+        hipLaunchKernelGGL(k_frame_rows, dim3(1), dim3(256), 0, stream, H, rp.rank, rp.nranks, rp.tile_rows, halo ? 1u : 0u, (uint32_t*)w.rows.p);
+        HIP_TRY(hipGetLastError());
     }
-    const uint32_t num_rows = (uint32_t)w.rows_host.size();
 
     int e;
     if ((e = w.color.ensure(npix * 3 * sizeof(double))) != RT_OK) return e;
@@ -530,7 +528,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     const uint32_t tiles = ((W + 7) / 8) * ((num_rows + 7) / 8);
     const uint32_t max_waves = (uint32_t)s->num_cus * trace_waves_per_cu();   // default: two waves per SIMD, all the register file allows
     if (!wavefront && (e = w.lane_mem.ensure((size_t)max_waves * 64 * RT_LANE_BYTES)) != RT_OK) return e;
-    HIP_TRY(hipEventRecord(s->ev[0], stream));
+    if (!fixed_mem) HIP_TRY(hipEventRecord(s->ev[0], stream));
     // ray-stack bound: every level pops one ray and pushes at most max_ray_spawn, plus the shadow tests of the last hit
     // Queries per trip.  Depth-first order (one ray per trip) needs at most per_level x depth + spawn + 1
     // stack entries; several rays per trip are taken only while what they may push still leaves that much room.
@@ -695,7 +693,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         int lrc = wavefront ? run_wavefront(0, (double*)w.color.p) : run_rounds(0, std::min(tiles, max_waves), (double*)w.color.p);
         if (lrc != RT_OK) return lrc;
     }
-    HIP_TRY(hipEventRecord(s->ev[1], stream));
+    if (!fixed_mem) HIP_TRY(hipEventRecord(s->ev[1], stream));
     if (aa_pass) {
         uint32_t blocks = (uint32_t)((npix + 255) / 256);
         hipLaunchKernelGGL(k_aa_detect, dim3(blocks), dim3(256), 0, stream, rp, (const double*)w.color.p, (const double*)w.distance.p,
@@ -708,16 +706,18 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                            (const double*)w.samples.p, (double*)w.color.p, (double*)w.distance.p);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s->ev[2], stream));
+    if (!fixed_mem) HIP_TRY(hipEventRecord(s->ev[2], stream));
     if (d_rgb) {
         uint32_t blocks = (uint32_t)((npix + 255) / 256);
         hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, stream, rp, (const double*)w.color.p, d_rgb);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s->ev[3], stream));
+    if (!fixed_mem) HIP_TRY(hipEventRecord(s->ev[3], stream));
     s->last_used_queues = wavefront;
     if (wavefront) HIP_TRY(hipMemcpyAsync(s->h_dropped, s->wf_sticky.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(s->ev_done, stream));
+    // (a frame in the static scratch array is made of kernel launches, memsets and one copy to pinned memory only: no
+    // events of the scene's, so that the sequence can be captured into a HIP graph)
+    if (!fixed_mem) HIP_TRY(hipEventRecord(s->ev_done, stream));
     s->timed = true;
     w.acc_dirty = false;
     return RT_OK;
@@ -815,13 +815,23 @@ int rt_render_device_noalloc(const RtScene* scene, const RtImageDim* dim, const 
     void* base = nullptr;
     { std::lock_guard<std::mutex> gl(g_scratch_mu); base = g_scratch_ptr[s->device]; }
     if (!base) return fail(RT_ERR_DEVICE, "rt_render_device_noalloc: the scratch array of this device was never looked up");
-    if (s->last_used_queues) (void)note_drops(s);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(stream, &capture));
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    if (s->last_used_queues && !capturing) (void)note_drops(s);
     Arena arena;
     arena.base = static_cast<uint8_t*>(base); arena.capacity = RT_NOALLOC_SCRATCH_BYTES; arena.used = 0;
     Workspace w;                         // every buffer of the frame: bump-allocated in the arena, all of it re-initialised by the frame
     w.use(&arena);
-    rc = enqueue_frame(s, w, *dim, *cam, *cfg, d_rgb_out, false, static_cast<hipStream_t>(hip_stream));
+    // Frames that use the array take turns on it: each waits for the event recorded behind the one before, whichever
+    // scene and stream that was on.  (Not under stream capture, where an event of another stream cannot be waited for:
+    // graphs that contain this call must be kept apart by their owner.)
+    std::lock_guard<std::mutex> turn(g_scratch_mu);
+    if (!capturing) HIP_TRY(hipStreamWaitEvent(stream, g_scratch_free[s->device], 0));
+    rc = enqueue_frame(s, w, *dim, *cam, *cfg, d_rgb_out, false, stream);
     if (rc != RT_OK) return rc;
+    if (!capturing) HIP_TRY(hipEventRecord(g_scratch_free[s->device], stream));
     s->last_noalloc = true;
     return RT_OK;
 }
@@ -831,6 +841,7 @@ int rt_last_timings(const RtScene* scene, double* ms_pass1, double* ms_aa, doubl
     RtScene* s = const_cast<RtScene*>(scene);
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->timed) return fail(RT_ERR_INVALID_ARG, "rt_last_timings: no frame rendered yet");
+    if (s->last_noalloc) return fail(RT_ERR_UNSUPPORTED, "rt_last_timings: frames of rt_render_device_noalloc record no events");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev[3]));
     float a = 0, b = 0, c = 0;
@@ -850,7 +861,7 @@ int rt_frame_status(const RtScene* scene, uint64_t* dropped) {
     if (dropped) *dropped = 0;
     if (!s->timed) return fail(RT_ERR_INVALID_ARG, "rt_frame_status: no frame rendered yet");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipEventSynchronize(s->ev_done));
+    if (!s->last_noalloc) HIP_TRY(hipEventSynchronize(s->ev_done));   // (a frame of rt_render_device_noalloc records no event: its caller has synchronised the stream)
     if (s->last_used_queues) (void)note_drops(s);
     const unsigned int lost = s->dropped_seen - s->dropped_reported;
     s->dropped_reported = s->dropped_seen;
@@ -942,20 +953,23 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
     double ms_a = 0, ms_b = 0, ms_c = 0;
     const bool have_ms = rt_last_timings(scene, &ms_a, &ms_b, &ms_c) == RT_OK;
     if (aux && have_ms) { aux->ms_pass1 = ms_a; aux->ms_aa = ms_b; aux->ms_encode = ms_c; }
-    if (s->progress) {   // the stages of src/progress_tracker.rs:59-73, after the fact
+    RtProgressFn progress = nullptr;
+    void* progress_user = nullptr;
+    { std::lock_guard<std::mutex> lk(s->mu); progress = s->progress; progress_user = s->progress_user; }
+    if (progress) {   // the stages of src/progress_tracker.rs:59-73, after the fact
         unsigned int flagged = 0;
         {
             std::lock_guard<std::mutex> lk(s->mu);
             if (cfg->anti_alias) HIP_TRY(hipMemcpy(&flagged, static_cast<char*>(s->ws.scalars.p) + SC_AA_COUNT * 4, sizeof flagged, hipMemcpyDeviceToHost));
         }
         const uint64_t traced = (uint64_t)rt_owned_rows_capacity(dim->height, cfg->nranks, cfg->tile_rows) * dim->width;
-        s->progress(s->progress_user, RT_PROGRESS_START, 0, npix, 0.0);
-        s->progress(s->progress_user, RT_PROGRESS_PASS1, std::min<uint64_t>(traced, npix), npix, ms_a * 1e-3);
+        progress(progress_user, RT_PROGRESS_START, 0, npix, 0.0);
+        progress(progress_user, RT_PROGRESS_PASS1, std::min<uint64_t>(traced, npix), npix, ms_a * 1e-3);
         if (cfg->anti_alias) {
-            s->progress(s->progress_user, RT_PROGRESS_START_AA, 0, flagged, ms_a * 1e-3);
-            s->progress(s->progress_user, RT_PROGRESS_AA, flagged, flagged, (ms_a + ms_b) * 1e-3);
+            progress(progress_user, RT_PROGRESS_START_AA, 0, flagged, ms_a * 1e-3);
+            progress(progress_user, RT_PROGRESS_AA, flagged, flagged, (ms_a + ms_b) * 1e-3);
         }
-        s->progress(s->progress_user, RT_PROGRESS_END, npix, npix, (ms_a + ms_b + ms_c) * 1e-3);
+        progress(progress_user, RT_PROGRESS_END, npix, npix, (ms_a + ms_b + ms_c) * 1e-3);
     }
     return RT_OK;
 }

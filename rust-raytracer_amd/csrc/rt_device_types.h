@@ -94,6 +94,16 @@ struct DMeshTri {              // one mesh face in BVH order (mesh.rs:416-466 in
     uint32_t i1, i2, i3, face;
 };
 
+// What shading needs of a mesh face beyond its DMeshTri, in BVH order like it: the normals and texture
+// coordinates of its three corners, gathered once on the host so that a hit fetches them with one read
+// alongside the triangle instead of following three vertex indices (mesh.rs:449-461).
+struct DMeshAttr {
+    double n1[3], n2[3], n3[3];
+    double uv[6];              // (u, v) of the corners
+    uint32_t flags;            // bit 0: the mesh has a normal for the face's first vertex index (mesh.rs:449), bit 1: a texture coordinate (:455)
+    uint32_t _pad;
+};
+
 // Copies of the BVH for the LDS-resident walk: boxes rounded outward to f32 (they only cull;
 // every arithmetic step still runs in f64), triangles without their attribute indices.
 struct LBvhNode {              // 64 bytes
@@ -110,7 +120,7 @@ struct LMeshTri {              // 64 bytes: vertices as f32 (exact: only used wh
 struct DMesh {
     uint32_t node_off, tri_off, num_tris, num_nodes;
     uint32_t lds_node_off, lds_tri_off;   // byte offsets into the scene's LDS blob
-    uint32_t normal_off, uv_off;   // into mesh_normals (3/vertex) and mesh_uvs (2/vertex)
+    uint32_t normal_off, uv_off;   // (unused: the corners' attributes are gathered per face, DMeshAttr)
     uint32_t num_normals, num_uvs;
     double lo[3], hi[3];
     double max_abs;            // largest |coordinate| of any node box (bounds the rounding error of the f32 box test)
@@ -203,8 +213,7 @@ struct DScene {
     const DMesh* meshes;
     const DBvhNode* bvh_nodes;
     const DMeshTri* mesh_tris;
-    const double* mesh_normals;
-    const double* mesh_uvs;
+    const DMeshAttr* mesh_attrs;     // one per mesh_tris entry
     const DCsgRoot* csg_roots;
     const DCsgOp* csg_ops;
     const DCsgLeaf* csg_leaves;

@@ -13,6 +13,8 @@
 //     flattened list of normal maps its modify_intersect applies (shader.rs:146-152).
 //   * Box<dyn Compositable> trees → a postfix program over leaves with composed transforms.
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -29,6 +31,17 @@ namespace rtflat {
 
 struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Invalid : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DeviceFailure : std::runtime_error { using std::runtime_error::runtime_error; };   // a HIP call failed while a scene was prepared on the device
+
+// Puts the calling thread's current HIP device back when it goes out of scope: the entry points that pick a
+// device of their own must not leave a caller that works on another GPU (a torch process, say) on theirs.
+struct DeviceRestore {
+    int saved = -1;
+    DeviceRestore() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceRestore() { if (saved >= 0) (void)hipSetDevice(saved); }
+    DeviceRestore(const DeviceRestore&) = delete;
+    DeviceRestore& operator=(const DeviceRestore&) = delete;
+};
 
 // ---- 4x4 column-major helpers (m[c*4+r]) ----
 struct Mat4 { double m[16]; };
@@ -134,7 +147,7 @@ struct FlatScene {
     std::vector<DMesh> meshes;
     std::vector<DBvhNode> bvh_nodes;
     std::vector<DMeshTri> mesh_tris;
-    std::vector<double> mesh_normals, mesh_uvs;
+    std::vector<DMeshAttr> mesh_attrs;
     std::vector<DCsgRoot> csg_roots;
     std::vector<DCsgOp> csg_ops;
     std::vector<DCsgLeaf> csg_leaves;
@@ -315,12 +328,32 @@ inline uint32_t flatten_mesh(FlatScene& fs, const RtSceneDesc& d, const RtMesh& 
         }
     }
     dm.num_nodes = (uint32_t)fs.bvh_nodes.size() - dm.node_off;
-    dm.normal_off = (uint32_t)(fs.mesh_normals.size() / 3);
-    dm.num_normals = m.num_normals;
-    fs.mesh_normals.insert(fs.mesh_normals.end(), d.mesh_f64 + m.normals_off, d.mesh_f64 + m.normals_off + 3 * (size_t)m.num_normals);
-    dm.uv_off = (uint32_t)(fs.mesh_uvs.size() / 2);
-    dm.num_uvs = m.num_texcoords;
-    fs.mesh_uvs.insert(fs.mesh_uvs.end(), d.mesh_f64 + m.texcoords_off, d.mesh_f64 + m.texcoords_off + 2 * (size_t)m.num_texcoords);
+    dm.normal_off = 0; dm.num_normals = m.num_normals;
+    dm.uv_off = 0; dm.num_uvs = m.num_texcoords;
+    // the corners' normals and texture coordinates per face, in BVH order (a vertex index beyond an array reads as
+    // zeros and is never used: the reference indexes with all three once the first is in range, mesh.rs:449-461)
+    fs.mesh_attrs.reserve(fs.mesh_attrs.size() + m.num_faces);
+    for (uint32_t i = 0; i < m.num_faces; ++i) {
+        const DMeshTri& t = fs.mesh_tris[dm.tri_off + i];
+        const uint32_t idx[3] = {t.i1, t.i2, t.i3};
+        DMeshAttr at{};
+        double* nn[3] = {at.n1, at.n2, at.n3};
+        if (m.num_normals > t.i1) {
+            at.flags |= 1u;
+            for (int c = 0; c < 3; ++c) {
+                if (idx[c] >= m.num_normals) throw Invalid("mesh face refers to a normal beyond the mesh's normals");
+                for (int k = 0; k < 3; ++k) nn[c][k] = d.mesh_f64[m.normals_off + 3 * (size_t)idx[c] + k];
+            }
+        }
+        if (m.num_texcoords > t.i1) {
+            at.flags |= 2u;
+            for (int c = 0; c < 3; ++c) {
+                if (idx[c] >= m.num_texcoords) throw Invalid("mesh face refers to a texture coordinate beyond the mesh's");
+                for (int k = 0; k < 2; ++k) at.uv[2 * c + k] = d.mesh_f64[m.texcoords_off + 2 * (size_t)idx[c] + k];
+            }
+        }
+        fs.mesh_attrs.push_back(at);
+    }
     // LDS copies: f32 boxes rounded outward, triangles without indices (only while the scene's meshes can still fit
     // a CU's LDS together: a larger scene walks the f64 records in global memory and needs no copies)
     if (fs.lds_blob.size() + ((size_t)dm.num_nodes + dm.num_tris) * 64u > RT_LDS_BLOB_MAX) { fs.lds_exact = false; fs.lds_blob.clear(); }

@@ -402,6 +402,7 @@ k_build_level(TriArray src, TriArray dst, GNode* nodes, uint32_t level_start, ui
 void device_build(int device, const double* P, uint32_t npos, const uint32_t* F, uint32_t nfaces, int max_depth,
                   std::vector<uint32_t>& face_order, std::vector<rtflat::BuildNode>& bn) {
     const auto t_begin = std::chrono::steady_clock::now();
+    rtflat::DeviceRestore restore;
     try {
         ING_HIP(hipSetDevice(device));
         Pool pool;
@@ -475,7 +476,7 @@ void device_build(int device, const double* P, uint32_t npos, const uint32_t* F,
                          std::chrono::duration<double, std::milli>(t_levels - t_begin).count(), std::chrono::duration<double, std::milli>(t_copied - t_levels).count(),
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copied).count());
     } catch (const HipFailure& e) {
-        throw std::runtime_error("device hierarchy build: " + e.what);
+        throw rtflat::DeviceFailure("device hierarchy build: " + e.what);
     }
 }
 
@@ -760,6 +761,7 @@ int obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ing_fail(RT_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return ing_fail(RT_ERR_INVALID_ARG, "device index out of range");
     const uint32_t n = (uint32_t)bytes;
+    rtflat::DeviceRestore restore;
     try {
         ING_HIP(hipSetDevice(device));
         Pool pool;
@@ -864,6 +866,10 @@ int obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out) {
         std::free(out->positions); std::free(out->normals); std::free(out->texcoords); std::free(out->faces);
         std::memset(out, 0, sizeof *out);
         return ing_fail(RT_ERR_DEVICE, "rt_obj_parse: " + e.what);
+    } catch (const std::exception& e) {                               // (std::bad_alloc of the host-side vectors: nothing may unwind through the C ABI)
+        std::free(out->positions); std::free(out->normals); std::free(out->texcoords); std::free(out->faces);
+        std::memset(out, 0, sizeof *out);
+        return ing_fail(RT_ERR_DEVICE, std::string("rt_obj_parse: ") + e.what());
     }
 }
 

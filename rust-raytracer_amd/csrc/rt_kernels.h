@@ -427,7 +427,37 @@ k_trace(DScene gsc, DRenderParams rp, TraceArgs a) {
 }
 
 // ------------------------------------------------------------------ accumulators -> f64
+// Does this rank render image row y?  Its own row blocks (block b belongs to rank b % nranks), plus - when the AA
+// detector will run - the row above and below each, so that the 8-neighbour stencil needs no exchange.
+__host__ __device__ inline bool rt_rank_renders_row(uint32_t y, uint32_t H, uint32_t rank, uint32_t nranks, uint32_t tile_rows, bool halo) {
+    if (nranks <= 1) return true;
+    if ((y / tile_rows) % nranks == rank) return true;
+    if (!halo) return false;
+    return (y > 0 && ((y - 1) / tile_rows) % nranks == rank) || (y + 1 < H && ((y + 1) / tile_rows) % nranks == rank);
+}
+
 #ifdef RT_FRAME_KERNELS   // (the kernels from here on are not templates: compiled once, by the file that launches them)
+// The rows this rank renders, ascending, written by the device itself (one workgroup; a frame has a few thousand
+// rows): the frame needs no upload and no host synchronisation for them.
+__global__ void __launch_bounds__(256)
+k_frame_rows(uint32_t H, uint32_t rank, uint32_t nranks, uint32_t tile_rows, uint32_t halo, uint32_t* __restrict__ rows) {
+    __shared__ uint32_t wave_total[4];
+    uint32_t base = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t y0 = 0; y0 < H; y0 += 256u) {
+        const uint32_t y = y0 + threadIdx.x;
+        const bool need = y < H && rt_rank_renders_row(y, H, rank, nranks, tile_rows, halo != 0u);
+        const unsigned long long m = __ballot(need);
+        if (lane == 0) wave_total[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 4u; ++w) { if (w < wave) before += wave_total[w]; all += wave_total[w]; }
+        if (need) rows[base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = y;
+        base += all;
+        __syncthreads();
+    }
+}
+
 // One accumulator per sample slot; dst is the colour buffer (pass 1) or the AA sample buffer.
 // Leaves every accumulator zero again.
 __global__ void __launch_bounds__(256)

@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include "rt_flatten.hpp"   // DeviceRestore
+
 #include "rt_amd.h"
 
 int rt_set_error(int code, const std::string& msg);   // rt_api.hip: the message rt_last_error returns on this thread
@@ -187,7 +189,12 @@ int write_png_device(int device, const uint8_t* d_rgb, uint32_t width, uint32_t 
 extern "C" {
 
 int rt_write_png_device(int device, const uint8_t* d_rgb, uint32_t width, uint32_t height, const char* file_name, void* hip_stream) {
-    return write_png_device(device, d_rgb, width, height, file_name, static_cast<hipStream_t>(hip_stream));
+    rtflat::DeviceRestore restore;
+    try {
+        return write_png_device(device, d_rgb, width, height, file_name, static_cast<hipStream_t>(hip_stream));
+    } catch (const std::exception& e) {                                   // (std::bad_alloc: nothing may unwind through the C ABI)
+        return out_fail(RT_ERR_DEVICE, std::string("rt_write_png_device: ") + e.what());
+    }
 }
 
 int rt_write_png(int device, const uint8_t* rgb, uint32_t width, uint32_t height, const char* file_name) {
@@ -196,13 +203,19 @@ int rt_write_png(int device, const uint8_t* rgb, uint32_t width, uint32_t height
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return out_fail(RT_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return out_fail(RT_ERR_INVALID_ARG, "device index out of range");
+    rtflat::DeviceRestore restore;
     OUT_TRY(hipSetDevice(device));
     const size_t bytes = 3u * (size_t)width * height;
     uint8_t* d = nullptr;
     OUT_TRY(hipMalloc((void**)&d, bytes));
     hipError_t e = hipMemcpy(d, rgb, bytes, hipMemcpyHostToDevice);
-    int rc = e == hipSuccess ? write_png_device(device, d, width, height, file_name, nullptr)
+    int rc;
+    try {
+        rc = e == hipSuccess ? write_png_device(device, d, width, height, file_name, nullptr)
                              : out_fail(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    } catch (const std::exception& ex) {
+        rc = out_fail(RT_ERR_DEVICE, std::string("rt_write_png: ") + ex.what());
+    }
     (void)hipFree(d);
     return rc;
 }

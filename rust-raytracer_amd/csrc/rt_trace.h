@@ -268,7 +268,7 @@ RT_DEV bool polyhedron_hit(const DScene& sc, const DPrim& ph, const LRay& r, dou
 }
 
 // ------------------------------------------------------------------ mesh (src/mesh.rs)
-RT_DEV void mesh_details(const DScene& sc, const DMesh& m, const DMeshTri& tr, const LRay& r, double t, Details& o) {   // :429-462
+RT_DEV void mesh_details(const DMeshTri& tr, const DMeshAttr& at, const LRay& r, double t, Details& o) {   // :429-462
     d3 v1 = ld3(tr.v1), v2 = ld3(tr.v2), v3 = ld3(tr.v3);
     o.p = r.o + (t * r.d);
     d3 vv = cross(v2 - v1, o.p - v1);
@@ -276,16 +276,11 @@ RT_DEV void mesh_details(const DScene& sc, const DMesh& m, const DMeshTri& tr, c
     double u = length(uu) * tr.inv_area;
     double v = length(vv) * tr.inv_area;
     double w = 1.0 - u - v;
-    if (m.num_normals > tr.i1) {
-        const double* N = sc.mesh_normals + 3 * (size_t)m.normal_off;
-        o.n = w * ld3(N + 3 * (size_t)tr.i1) + u * ld3(N + 3 * (size_t)tr.i2) + v * ld3(N + 3 * (size_t)tr.i3);
-    } else {
-        o.n = ld3(tr.n);
-    }
-    if (m.num_uvs > tr.i1) {
-        const double* T = sc.mesh_uvs + 2 * (size_t)m.uv_off;
-        double tx = (T[2 * (size_t)tr.i1] * w + T[2 * (size_t)tr.i2] * u) + T[2 * (size_t)tr.i3] * v;
-        double ty = (T[2 * (size_t)tr.i1 + 1] * w + T[2 * (size_t)tr.i2 + 1] * u) + T[2 * (size_t)tr.i3 + 1] * v;
+    if (at.flags & 1u) o.n = w * ld3(at.n1) + u * ld3(at.n2) + v * ld3(at.n3);
+    else o.n = ld3(tr.n);
+    if (at.flags & 2u) {
+        double tx = (at.uv[0] * w + at.uv[2] * u) + at.uv[4] * v;
+        double ty = (at.uv[1] * w + at.uv[3] * u) + at.uv[5] * v;
         surface_coord(tx, ty, o.u, o.v);
     } else {
         surface_coord(0.0, 0.0, o.u, o.v);
@@ -705,7 +700,7 @@ RT_DEV void basic_details(const DScene& sc, const DPrim& p, const LRay& r, const
         case DP_MESH:
             if constexpr (F & RTF_MESH) {
                 const DMesh& m = sc.meshes[p.ref];
-                mesh_details(sc, m, sc.mesh_tris[m.tri_off + c.a], r, c.t, o);
+                mesh_details(sc.mesh_tris[m.tri_off + c.a], sc.mesh_attrs[m.tri_off + c.a], r, c.t, o);
             }
             break;
         default: break;

@@ -6,6 +6,9 @@
 // variant lives in a source file of its own under variants/ (they compile side by side); the frame
 // driver in rt_api.hip only sees the launch functions declared here.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 // (the translation units of the persistent trace kernel define RT_VARIANT_TRACE_ONLY: they do not depend on
 // the queue pipeline's header, and are not rebuilt when it changes)
 #ifdef RT_VARIANT_TRACE_ONLY
@@ -35,6 +38,23 @@ struct LaunchStatus {             // hipSuccess, or the failing call
     const char* what;
 };
 
+// Raises a kernel's dynamic-LDS limit on the current device when a launch needs more than it has been granted so
+// far.  The attribute sticks, so remembering the grant keeps the call out of every later launch: the frame's
+// launch sequence is then made of stream operations only (it can be captured into a HIP graph once it has run once).
+inline hipError_t rt_grant_lds(const void* fn, uint32_t lds) {
+    if (lds <= 48u * 1024u) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, uint32_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    uint32_t& g = granted[{dev, fn}];
+    if (lds <= g) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) g = lds;
+    return e;
+}
+
 #define RT_DECLARE_TRACE(name, F) \
     LaunchStatus rt_launch_trace_##name(bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const TraceArgs& ta);
 RT_TRACE_VARIANTS(RT_DECLARE_TRACE)
@@ -56,7 +76,7 @@ LaunchStatus launch_trace_variant(bool count, uint32_t grid, hipStream_t stream,
     if (F & RTF_MESH) lds = RT_LDS_FIXED_BYTES(block) + ((F & RTF_LDS_BVH) ? ds.lds_blob_bytes : 0u);   // walk stacks, job lists (+ blob)
     if (lds > 48u * 1024u) {
         auto fn = count ? (const void*)k_trace<F, true> : (const void*)k_trace<F, false>;
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t ea = rt_grant_lds(fn, lds);
         if (ea != hipSuccess) return {ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"};
     }
     // Scenes whose lights are sampled inside the shader and that have no meshes: every shadow test reads the
@@ -99,7 +119,7 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
                      : (count ? (const void*)k_wf_analytic<F, true, false, true> : (const void*)k_wf_analytic<F, false, false, true>);
     }
     if (!fn) return {hipErrorInvalidValue, "queue-pipeline kernel selection"};
-    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)rt_grant_lds(fn, lds);
     void* params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, stream);
     return {hipGetLastError(), "queue-pipeline kernel launch"};

@@ -11,8 +11,8 @@ LaunchStatus rt_launch_wf_walk(bool count, uint32_t num_cus, hipStream_t stream,
     const uint32_t lds = RT_WF_WALK_FIXED_BYTES(block) + (lds_bvh ? ds.lds_blob_bytes : 0u);   // walk stacks, list starts (+ blob)
     const void* fn = lds_bvh ? (count ? (const void*)k_wf_walk<true, true> : (const void*)k_wf_walk<true, false>)
                              : (count ? (const void*)k_wf_walk<false, true> : (const void*)k_wf_walk<false, false>);
-    if (lds > 48u * 1024u) {
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t ea = rt_grant_lds(fn, lds);
         if (ea != hipSuccess) return {ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"};
     }
     if (lds_bvh) {
