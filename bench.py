@@ -15,15 +15,20 @@ here has touched the GPU), relays its output and exits with its status.
 
 ray        = one closest-hit query that passed the depth/contribution gate, or one any-hit
              shadow query (counted on device by an instrumented, untimed frame)
-roofline   = FP64 vector ALU: algorithmic flops (fixed cost per counted unit of work, see
-             fill_counters in csrc/rt_api.hip; the counted units are in `work`) of the longer of
-             the two trace passes / its HIP-event duration, against the 78.6 TFLOP/s FP64 vector
-             peak (which assumes fused multiply-adds; the path is built with -ffp-contract=off
-             like the reference's arithmetic, so what it can reach is `peak_no_fma`).  A pass is
-             one launch sequence of the queue pipeline (analytic / BVH walk / settle / shade per
-             ray generation); the events bracket the whole sequence on the launch stream.
-             `traffic` = HBM bytes per frame from rocprofv3 FETCH_SIZE / WRITE_SIZE passes of
-             this command, read from the committed summary profiles/hbm_traffic.json
+roofline   = vector ALU: algorithmic flops (fixed cost per counted unit of work, see fill_counters
+             in csrc/rt_api.hip; the counted units are in `work`) of the longer of the two trace
+             passes / its HIP-event duration.  The flops are split by the arithmetic they ran in:
+             f64 against the FP64 vector peak, and the box tests of the
+             LDS-resident BVH walk, which run as packed f32, against the FP32 vector peak (`f32`).
+             `peak` is the datasheet figure (78.6 TFLOP/s FP64 with FMA; the path is built with
+             -ffp-contract=off like the reference's arithmetic, so what it can issue is
+             `peak_no_fma`); `peak_measured` is what tools/peaks.hip reached on an MI355X
+             (profiles/r03_peaks.json).  A pass is one launch sequence of the queue pipeline
+             (analytic / BVH walk / settle / shade per ray generation); the events bracket the whole
+             sequence on the launch stream.
+             `traffic` = HBM bytes of that pass from rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
+             workload, read from the committed summary profiles/hbm_traffic.json - only while the
+             kernel sources are the ones the summary was taken with (`kernels` hash), else null
 cpu_baseline = the CPU restatement of the reference (oracle/, 8 threads like the
              reference's default pool, and all host cores) on a bounded sample of the same frame
 """
@@ -49,7 +54,28 @@ CONFIGS = {
 TILE_ROWS = 8     # rows per block of the multi-GPU split (measured on 1080p: 8 balances the ranks best; 4 pays too much halo)
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, FP64 vector with FMA (half the 157.3 TF FP32 vector rate)
 FP64_VECTOR_PEAK_NO_FMA_TFLOPS = 39.3   # one flop per lane and cycle: what un-fused arithmetic can issue
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # packed FP32 FMA
 HBM_PEAK_GBS = 8000.0
+
+
+def measured_peaks():
+    """What tools/peaks.hip measured on an MI355X (committed under profiles/), or {}."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_peaks.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def kernel_sources_hash():
+    """Identifies the device code: sha256 over the kernel sources (csrc/*.h, *.hpp, *.hip and the variants)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "rust-raytracer_amd", "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hpp", ".hip")))
+    names += sorted(os.path.join("variants", f) for f in os.listdir(os.path.join(csrc, "variants")) if f.endswith(".hip"))
+    for n in names:
+        h.update(n.encode() + b"\0" + open(os.path.join(csrc, n), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse_args():
@@ -113,6 +139,8 @@ def measured_traffic(config, n_gpus):
         return None, None
     if not rec:
         return None, None
+    if rec.get("kernels") != kernel_sources_hash():
+        return None, {"stale": True, "source": rec.get("source"), "kernels": rec.get("kernels")}   # the kernels have changed since the counters were read
     return rec.get("bytes_per_frame"), rec
 
 
@@ -170,14 +198,17 @@ def main():
     p1 = counted(False)
     keys = ["rays_total", "rays_primary", "rays_secondary", "rays_shadow", "rays_aa", "aa_pixels", "instance_tests",
             "box_tests", "tri_tests", "shade_evals", "stack_overflows"]
-    t = torch.tensor([float(full[k]) for k in keys] + [float(p1["flops"]), float(full["flops"] - p1["flops"])],
+    keys += ["box_tests_f32", "csg_events"]
+    t = torch.tensor([float(full[k]) for k in keys] + [float(p1["flops"]), float(full["flops"] - p1["flops"]),
+                                                        float(p1["flops_f32"]), float(full["flops_f32"] - p1["flops_f32"])],
                      dtype=torch.float64, device=device)
     local = t.clone()
     if world > 1:
         dist.all_reduce(t)
     work = {k: int(v) for k, v in zip(keys, t[:len(keys)].tolist())}
     rays_total = float(work["rays_total"])
-    flops_pass1, flops_aa = float(local[-2].item()), float(local[-1].item())   # of this rank's share: the roofline line is rank 0's
+    flops_pass1, flops_aa = float(local[-4].item()), float(local[-3].item())   # of this rank's share: the roofline line is rank 0's
+    f32_pass1, f32_aa = float(local[-2].item()), float(local[-1].item())        # ... of which in f32
     if work["stack_overflows"] != 0:
         raise RuntimeError("secondary-ray stack overflowed: results would be incomplete")
 
@@ -224,19 +255,37 @@ def main():
         launches = ("k_wf_analytic + k_wf_walk + k_wf_settle + k_wf_shade per generation" if full.get("schedule") == 1
                     else "k_trace, persistent lanes")
         if stage_ms["aa"] >= stage_ms["pass1"]:
-            which, kernel, k_ms, k_flops = "aa", f"AA-resolve pass ({launches})", stage_ms["aa"], flops_aa
+            which, kernel, k_ms, k_flops, k_f32 = "aa", f"AA-resolve pass ({launches})", stage_ms["aa"], flops_aa, f32_aa
         else:
-            which, kernel, k_ms, k_flops = "pass1", f"pass 1 ({launches})", stage_ms["pass1"], flops_pass1
-        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            which, kernel, k_ms, k_flops, k_f32 = "pass1", f"pass 1 ({launches})", stage_ms["pass1"], flops_pass1, f32_pass1
+        k_f64 = k_flops - k_f32
+        per_s = 1.0 / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        achieved, achieved_f32 = k_f64 * per_s, k_f32 * per_s
+        peaks = measured_peaks()
         fb_bytes = width * height * (32 + 3)   # f64 colour+distance written once, RGB8 written once
         traffic, traffic_rec = measured_traffic(args.config, world)
         roofline = {"bound": "valu_fp64", "kernel": kernel, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                     "peak_no_fma": FP64_VECTOR_PEAK_NO_FMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "frac_no_fma": achieved / FP64_VECTOR_PEAK_NO_FMA_TFLOPS,
-                    "traffic": (traffic_rec or {}).get("bytes_" + which), "traffic_per_frame": traffic,
-                    "algorithmic_flops_per_launch": int(k_flops), "avg_launch_ms": k_ms,
+                    "f32": {"achieved": achieved_f32, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_f32 / FP32_VECTOR_PEAK_TFLOPS,
+                            "what": "box tests of the LDS-resident BVH walk (packed f32 FMA, v_min3 / v_max3), 24 flop each"},
+                    # f64 and f32 work share the same SIMDs and the same time: the two fractions add up
+                    "frac_f64_plus_f32": achieved / FP64_VECTOR_PEAK_TFLOPS + achieved_f32 / FP32_VECTOR_PEAK_TFLOPS,
+                    "traffic": None if not traffic_rec or traffic_rec.get("stale") else traffic_rec.get("bytes_" + which),
+                    "traffic_per_frame": traffic,
+                    "algorithmic_flops_per_launch": int(k_flops), "algorithmic_flops_f64": int(k_f64), "algorithmic_flops_f32": int(k_f32),
+                    "avg_launch_ms": k_ms, "kernels": kernel_sources_hash(),
                     "hbm_secondary": {"algorithmic_bytes_per_frame": fb_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "achieved_algorithmic": fb_bytes / (ms_per_step * 1e-3) / 1e9}}
+        if peaks:
+            roofline["peak_measured"] = peaks.get("fp64_fma_tflops")
+            roofline["peak_measured_no_fma"] = peaks.get("fp64_mul_add_tflops")
+            roofline["frac_measured"] = achieved / peaks["fp64_fma_tflops"] if peaks.get("fp64_fma_tflops") else None
+            roofline["f32"]["peak_measured"] = peaks.get("fp32_packed_fma_tflops")
+            roofline["hbm_secondary"]["peak_measured"] = peaks.get("hbm_read_gbs")
+            roofline["peaks_source"] = "profiles/r03_peaks.json (tools/peaks.hip on one MI355X)"
+        if traffic_rec and traffic_rec.get("stale"):
+            roofline["traffic_stale"] = "profiles/hbm_traffic.json was taken with other kernels (%s)" % traffic_rec.get("kernels")
         if traffic:
             roofline["hbm_secondary"]["achieved_measured"] = traffic / (ms_per_step * 1e-3) / 1e9
             roofline["hbm_secondary"]["traffic_source"] = traffic_rec.get("source")

@@ -243,7 +243,9 @@ pub struct RtCounters {
     pub flops: u64,
     pub schedule: u64,
     pub attempts: u64,
-    pub _reserved: [u64; 3],
+    pub box_tests_f32: u64,
+    pub csg_events: u64,
+    pub flops_f32: u64,
 }
 
 #[repr(C)]

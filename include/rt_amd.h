@@ -227,12 +227,15 @@ typedef struct RtCounters {
     uint64_t tri_tests;          /* mesh triangle tests                            */
     uint64_t shade_evals;        /* Phong light evaluations (Lit illums)           */
     uint64_t stack_overflows;    /* rays dropped because a fixed stack was full (must be 0) */
-    uint64_t flops;              /* algorithmic f64 flop estimate of the work above */
+    uint64_t flops;              /* algorithmic flop estimate of the work above and below (f64 + f32) */
     uint64_t schedule;           /* which schedule rendered the frame: 1 ray queues in HBM (one launch
                                     sequence per ray generation), 2 persistent kernel             */
     uint64_t attempts;           /* frames enqueued for this call: 1, or more when a ray generation
                                     outgrew the queues and the frame was redone with larger ones  */
-    uint64_t _reserved[3];
+    uint64_t box_tests_f32;      /* of box_tests: those run as packed-f32 slab tests (LDS-resident BVH walk) */
+    uint64_t csg_events;         /* leaf hits stepped through by composite-shape evaluations
+                                    (src/composite_shape.rs:111-121), 20 flop each in `flops`               */
+    uint64_t flops_f32;          /* the part of `flops` that ran in f32: 24 per f32 box test               */
 } RtCounters;
 
 /* Optional per-pixel outputs, all W*H (row-major, top row first) or NULL.

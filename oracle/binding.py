@@ -25,6 +25,8 @@ def lib():
         l.oracle_render.argtypes = [C.c_void_p, C.POINTER(_abi.RtImageDim), C.POINTER(_abi.RtCamera),
                                     C.POINTER(_abi.RtRenderConfig), C.c_void_p, C.POINTER(_abi.RtAux)]
         l.oracle_set_faithful_cost.argtypes = [C.c_int]
+        l.oracle_last_assert_failures.restype = C.c_ulonglong
+        l.oracle_last_assert_failures.argtypes = []
         _lib = l
     return _lib
 
@@ -50,5 +52,5 @@ def render(scene, dim, cam, cfg, want_aux=True, faithful_cost=False):
     if rc != 0:
         raise RuntimeError(f"oracle_render failed with status {rc}")
     out["counters"] = aux.counters.as_dict()
-    out["assert_failures"] = int(aux.counters._reserved[0])
+    out["assert_failures"] = int(l.oracle_last_assert_failures())
     return out

@@ -53,11 +53,13 @@ class RtCounters(C.Structure):
         ("flops", C.c_uint64),
         ("schedule", C.c_uint64),
         ("attempts", C.c_uint64),
-        ("_reserved", C.c_uint64 * 3),
+        ("box_tests_f32", C.c_uint64),
+        ("csg_events", C.c_uint64),
+        ("flops_f32", C.c_uint64),
     ]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "_reserved"}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_}
         d["rays_total"] = d["rays_primary"] + d["rays_secondary"] + d["rays_shadow"] + d["rays_aa"]
         return d
 

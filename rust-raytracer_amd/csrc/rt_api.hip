@@ -755,12 +755,16 @@ void fill_counters(RtCounters& out, const DCounters& c) {
     out.rays_primary = c.rays_primary; out.rays_secondary = c.rays_secondary; out.rays_shadow = c.rays_shadow; out.rays_aa = c.rays_aa;
     out.aa_pixels = c.aa_pixels; out.instance_tests = c.instance_tests; out.box_tests = c.box_tests; out.tri_tests = c.tri_tests;
     out.shade_evals = c.shade_evals; out.stack_overflows = c.stack_overflows;
-    // Algorithmic f64 flop estimate: fixed cost per unit of counted work —
-    // ray→instance transform + analytic primitive test 48, BVH box slab test 24, mesh triangle
-    // test 60, Phong per lit sample 40, hit→world + shading set-up 45 per closest-hit ray,
-    // reflect/refract/Fresnel 30 per secondary ray.
+    out.box_tests_f32 = c.box_tests_f32; out.csg_events = c.csg_events;
+    // Algorithmic flop estimate: fixed cost per unit of counted work -
+    // ray->instance transform + analytic primitive test 48, BVH box slab test 24, mesh triangle
+    // test 60, Phong per lit sample 40, hit->world + shading set-up 45 per closest-hit ray,
+    // reflect/refract/Fresnel 30 per secondary ray, composite-shape event 20.  `flops` is the sum; the box
+    // tests of the LDS-resident BVH walk run in packed f32 and are priced apart (flops_f32), against the
+    // f32 vector rate.
+    out.flops_f32 = 24 * c.box_tests_f32;
     out.flops = 48 * c.instance_tests + 24 * c.box_tests + 60 * c.tri_tests + 40 * c.shade_evals +
-                45 * (c.rays_primary + c.rays_secondary + c.rays_aa) + 30 * c.rays_secondary;
+                45 * (c.rays_primary + c.rays_secondary + c.rays_aa) + 30 * c.rays_secondary + 20 * c.csg_events;
 }
 
 }  // namespace

@@ -260,6 +260,8 @@ struct DRenderParams {
 struct DCounters {             // mirrors RtCounters' first ten fields
     unsigned long long rays_primary, rays_secondary, rays_shadow, rays_aa, aa_pixels,
         instance_tests, box_tests, tri_tests, shade_evals, stack_overflows;
+    unsigned long long box_tests_f32;   // of box_tests: those that ran as packed-f32 slab tests (the LDS-resident BVH walk)
+    unsigned long long csg_events;      // leaf hits a composite-shape evaluation stepped through (composite_shape.rs:111-121)
     // lane occupancy of the trace kernel's phases (instrumented launches only): per phase the
     // number of loop trips a wave made and the number of lanes that had work in them
     unsigned long long prof[16];

@@ -110,6 +110,8 @@ RT_DEV void flush_counters(DCounters* g, const Work<COUNT>& wk, unsigned long lo
     atomicAdd(&g->rays_shadow, wk.rays_shadow);
     atomicAdd(&g->instance_tests, wk.instance_tests);
     atomicAdd(&g->box_tests, wk.box_tests);
+    if (wk.box_tests_f32) atomicAdd(&g->box_tests_f32, wk.box_tests_f32);
+    if (wk.csg_events) atomicAdd(&g->csg_events, wk.csg_events);
     atomicAdd(&g->tri_tests, wk.tri_tests);
     atomicAdd(&g->shade_evals, wk.shade_evals);
     atomicAdd(&g->stack_overflows, wk.stack_overflows);

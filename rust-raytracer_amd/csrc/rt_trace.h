@@ -68,7 +68,7 @@ struct Details {         // Intersect fields in the primitive's own space (geome
 
 template <bool COUNT>
 struct Work {            // per-thread work counters, compiled out when COUNT is false
-    unsigned long long instance_tests, box_tests, tri_tests, shade_evals, rays_shadow, rays_secondary, stack_overflows;
+    unsigned long long instance_tests, box_tests, tri_tests, shade_evals, rays_shadow, rays_secondary, stack_overflows, box_tests_f32, csg_events;
     unsigned long long prof[16];
 };
 // Occupancy probe: one lane of the wave counts the trip, every lane with work counts itself.
@@ -412,7 +412,7 @@ RT_DEV bool mesh_walk(const DScene& sc, const DMesh& m, const LRay& r, bool any,
         while (!(cur & 0x80000000u)) {                         // descend to a leaf
             bool h0, h1, swap;
             uint32_t c0, c1;
-            if (COUNT) wk.box_tests += 2;
+            if (COUNT) { wk.box_tests += 2; if (LDS) wk.box_tests_f32 += 2; }
             if (LDS) {
                 float tn0, tn1;
                 const LBvhNode n = lds_node(lnodes + cur);
@@ -575,7 +575,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
             bool h0, h1, swap;
             uint32_t c0, c1;
-            if (COUNT) wk.box_tests += 2;
+            if (COUNT) { wk.box_tests += 2; if (LDS) wk.box_tests_f32 += 2; }
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             if (LDS) {
                 float tn0, tn1;
@@ -808,6 +808,7 @@ RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, C
                     if (pick < 0 || !(bt < t)) { pick = (int)i; bt = t; }
                 }
                 if (pick < 0) break;
+                RT_COUNT(wk, csg_events);
                 CsgHit h = arena[lbegin[base + pick] + cursor[pick]++];
                 int pr = csg_predicate(op.kind, (uint32_t)pick, states, k);
                 if (pr && no < RT_CSG_MAX_HITS) {
@@ -914,6 +915,7 @@ RT_DEV int csg_closest_fast(const DScene& sc, const DCsgRoot& root, const LRay& 
         }
         if (!(mt < INFINITY)) return 0;
         if (same) return 2;                                        // two events at one distance
+        RT_COUNT(wk, csg_events);
         inside_bits ^= 1u << (mk >> 1);
         const bool now = csg_value(sc, root, inside_bits);
         if (now != value) {

@@ -626,7 +626,7 @@ k_wf_walk(DScene sc, WfArgs a) {
             if ((uint32_t)__popcll(__ballot(true)) * 8u < nwalk * a.descend_frac) break;
             bool h0, h1, swap;
             uint32_t c0, c1;
-            if (COUNT) wk.box_tests += 2;
+            if (COUNT) { wk.box_tests += 2; if (LDS) wk.box_tests_f32 += 2; }
             RT_PROF(wk, PF_T_ITERS, PF_T_LANES);
             uint32_t top = 0;
             if (LDS) {

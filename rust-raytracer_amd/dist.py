@@ -35,23 +35,54 @@ def assemble(gathered, height, nranks, tile_rows):
     return gathered[owner, local]
 
 
+class FrameGather:
+    """The buffers of the multi-GPU frame loop, allocated once: this rank's compact row-block buffer, on rank 0 the
+    landing area of the gather (one slice per rank), the row map and the assembled frame.  A frame then costs the
+    render, one gather and one indexed copy; nothing is allocated inside the loop."""
+
+    def __init__(self, width, height, tile_rows, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.height, self.tile_rows = height, tile_rows
+        cap = owned_rows_capacity(height, self.world, tile_rows)
+        self.local = torch.zeros((cap, width, 3), dtype=torch.uint8, device=device)
+        self.parts = self.frame = self.index = None
+        if self.world > 1 and self.rank == 0:
+            self.landing = torch.zeros((self.world, cap, width, 3), dtype=torch.uint8, device=device)
+            self.parts = [self.landing[r] for r in range(self.world)]          # views: the gather writes straight into `landing`
+            owner, local = row_map(height, self.world, tile_rows, device)
+            self.index = owner * cap + local                                    # row y of the frame = row index[y] of landing.view(world * cap, W, 3)
+            self.frame = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
+
+    def render(self, render_local):
+        """Render this rank's share and gather the frame on rank 0: the assembled (H, W, 3) uint8 tensor there
+        (overwritten by the next call), None elsewhere."""
+        render_local(self.local, self.rank, self.world, self.tile_rows)
+        if self.world == 1:
+            return self.local[:self.height]
+        if self.rank == 0:
+            dist.gather(self.local, self.parts, dst=0, group=self.group)
+            torch.index_select(self.landing.view(-1, *self.landing.shape[2:]), 0, self.index, out=self.frame)
+            return self.frame
+        dist.gather(self.local, None, dst=0, group=self.group)
+        return None
+
+
+_gathers = {}
+
+
 def render_frame(render_local, width, height, tile_rows, device, group=None):
     """Render this rank's share and gather the frame on rank 0.
 
-    Returns the assembled (H, W, 3) uint8 tensor on rank 0 and None elsewhere."""
+    Returns the assembled (H, W, 3) uint8 tensor on rank 0 (valid until the next call with the same frame shape)
+    and None elsewhere.  The buffers behind it are kept per frame shape (FrameGather)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    cap = owned_rows_capacity(height, world, tile_rows)
-    local = torch.zeros((cap, width, 3), dtype=torch.uint8, device=device)
-    render_local(local, rank, world, tile_rows)
-    if world == 1:
-        return local[:height]
-    if rank == 0:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, parts, dst=0, group=group)
-        return assemble(torch.stack(parts), height, world, tile_rows)
-    dist.gather(local, None, dst=0, group=group)
-    return None
+    key = (width, height, tile_rows, str(device), world, id(group))
+    g = _gathers.get(key)
+    if g is None:
+        g = _gathers[key] = FrameGather(width, height, tile_rows, device, group)
+    return g.render(render_local)
 
 
 def hip_render_local(device_scene, dim, cam, cfg, check=True):

@@ -144,3 +144,42 @@ def test_describe_names_only_fields_the_reference_types_have():
         fields = set(re.findall(r"(?:pub )?(\w+)\s*:", sm.group(1)))
         for f in set(re.findall(r"self\.(\w+)\b(?!\()", body)):
             assert f in fields, (t, f, sorted(fields))
+
+
+def test_build_rs_builds_what_build_py_builds():
+    """ffi/build.rs must compile the library's translation units with the flags, and link the libraries, that
+    rust-raytracer_amd/build.py does: same source directories, same hipcc flags, same -l options."""
+    build_rs = open(os.path.join(ROOT, "ffi", "build.rs")).read()
+    build_py = open(os.path.join(ROOT, "rust-raytracer_amd", "build.py")).read()
+    # source directories: every *.hip under csrc/ and csrc/variants/, in both scripts
+    assert 'hip_sources(&csrc)' in build_rs and 'hip_sources(&csrc.join("variants"))' in build_rs
+    assert re.search(r'os\.listdir\(src_dir\) if f\.endswith\("\.hip"\)', build_py) and re.search(r'os\.listdir\(var_dir\) if f\.endswith\("\.hip"\)', build_py)
+    assert 'e == "hip"' in build_rs
+    # compile flags
+    rs_flags = re.search(r"const HIP_FLAGS: &\[&str\] = &\[(.*?)\];", build_rs, flags=re.S).group(1)
+    rs_flags = set(re.findall(r'"([^"]+)"', rs_flags))
+    py_flags = re.search(r"HIP_FLAGS = \[(.*?)\]\n", build_py, flags=re.S).group(1)
+    py_flags = set(re.findall(r'"(-[^"]+)"', py_flags)) - {"-shared"}
+    py_flags = {f if f != "-ffp-contract=" else "-ffp-contract=off" for f in py_flags}      # (the script's default)
+    assert rs_flags == py_flags, (rs_flags, py_flags)
+    # link libraries
+    rs_libs = set(re.findall(r'"(-l\w+|-pthread)"', re.search(r"const LINK_LIBS: &\[&str\] = &\[(.*?)\];", build_rs).group(1)))
+    py_link = re.search(r'_run\(\["hipcc", "--offload-arch=gfx950", "-shared".*?\]\)', build_py, flags=re.S).group(0)
+    py_libs = set(re.findall(r'"(-l\w+|-pthread)"', py_link))
+    assert rs_libs == py_libs and rs_libs, (rs_libs, py_libs)
+
+
+def test_every_declared_entry_point_is_defined_in_a_compiled_unit():
+    """Every rt_* function of the header (= of the crate's extern block, see above) has its definition in one of
+    the csrc/*.hip files both build scripts compile."""
+    text = strip_c_comments(HEADER)
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\([^)]*\)\s*;", text))
+    csrc = os.path.join(ROOT, "rust-raytracer_amd", "csrc")
+    units = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+    assert len(units) >= 3
+    defined = set()
+    for u in units:
+        src = open(u).read()
+        defined |= set(re.findall(r"^(?:int|void|uint32_t|const char\*)\s+(rt_[a-z_]+)\s*\([^;{]*\)\s*\{", src, flags=re.M))
+    missing = declared - defined
+    assert not missing, missing

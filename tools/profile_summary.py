@@ -3,7 +3,8 @@
 
   profiles/<tag>_<config>.txt     per kernel: dispatches, time, FETCH_SIZE / WRITE_SIZE, SQ ratios, per frame
   profiles/<tag>_pmc_hbm.txt      the calibration of the two traffic counters and the per-frame totals
-  profiles/hbm_traffic.json       HBM bytes per frame for each configuration (bench.py reads it)
+  profiles/hbm_traffic.json       HBM bytes per frame for each configuration, stamped with a hash of the kernel sources
+                                  (bench.py reads it, and ignores entries taken with other kernels)
 
 Usage: profile_summary.py <gpurun_out/dir> <tag>
 
@@ -69,6 +70,9 @@ def calibration():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_hash
+    kernels = kernel_sources_hash()             # bench.py uses an entry only while the kernel sources still hash to this
     calib_rows, f_read, f_write = calibration()
     traffic = {}
     hbm_lines = ["HBM traffic counters (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each), tools/collect_profiles.sh + tools/profile_summary.py",
@@ -125,7 +129,7 @@ def main():
         per_pass = {k: fp[k] * 1024 * f_read + wp[k] * 1024 * f_write for k in fp}
         lines.append("HBM per pass: pass 1 %.1f MB, AA resolve %.1f MB" % (per_pass["pass1"] / 1e6, per_pass["aa"] / 1e6))
         open(os.path.join(OUT, "%s_%s.txt" % (tag, config)), "w").write("\n".join(lines) + "\n")
-        traffic[config] = {"bytes_per_frame": tot_r + tot_w, "bytes_pass1": per_pass["pass1"], "bytes_aa": per_pass["aa"], "read_bytes": tot_r, "written_bytes": tot_w,
+        traffic[config] = {"kernels": kernels, "bytes_per_frame": tot_r + tot_w, "bytes_pass1": per_pass["pass1"], "bytes_aa": per_pass["aa"], "read_bytes": tot_r, "written_bytes": tot_w,
                            "fetch_size_kib": tot_r / 1024 / f_read, "write_size_kib": tot_w / 1024 / f_write,
                            "read_factor": f_read, "write_factor": f_write,
                            "source": "profiles/%s_pmc_hbm.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on 1 GiB streams (tools/hbm_calib.hip)" % tag}
@@ -133,7 +137,13 @@ def main():
             config, tot_r / 1e6, tot_w / 1e6, (tot_r + tot_w) / 1e6, tot_r / 1024 / f_read, tot_w / 1024 / f_write))
         print(config, "%.1f ms/frame, %.1f MB/frame" % (tot_ms, (tot_r + tot_w) / 1e6))
     open(os.path.join(OUT, "%s_pmc_hbm.txt" % tag), "w").write("\n".join(hbm_lines) + "\n")
-    json.dump(traffic, open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    path = os.path.join(OUT, "hbm_traffic.json")
+    try:
+        merged = json.load(open(path))          # configurations this run did not profile keep their (hash-stamped) entries
+    except (OSError, ValueError):
+        merged = {}
+    merged.update(traffic)
+    json.dump(merged, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
