@@ -96,7 +96,11 @@ enum {
                                   p[4] != 0: the shader's earlier revision, still present as a
                                   comment at translucent.rs:59 — one transmitted ray, no Fresnel
                                   split; the revision the reference's gallery/glass_monkey.png
-                                  was rendered with                                        */
+                                  was rendered with
+                                  p[5] != 0 (on the shader of a node): shadow tests pass through the
+                                  node's surface, as in the still older revision behind
+                                  gallery/subtraction_room.png (opacity BLACK, translucent.rs:64-66;
+                                  nothing in the current sources reads get_opacity)        */
     RT_SHADER_MIX = 4,         /* children                           shader.rs:52-54     */
     RT_SHADER_COMPOSITE = 5,   /* weighted children                  shader.rs:77-79     */
     RT_SHADER_CHAIN = 6,       /* children                           shader.rs:114-116   */

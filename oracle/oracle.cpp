@@ -56,6 +56,7 @@ unsigned long long g_last_assert_failures = 0;   // reference `assert!`s that wo
 bool g_mesh_brute_force = false;
 // Golden-image mode: TranslucentShader as it was when the reference's gallery image was rendered.
 bool g_legacy_translucent = false;
+bool g_legacy_square_light = false;    // diagnostic (gallery/light_room.png, monkey_1.png): SquareLight samples 400 uniform points, each shadow-tested
 bool g_legacy_clear_shadows = false;   // diagnostic (gallery/subtraction_room.png): a TranslucentShader surface lets the shadow test pass
 
 #define ORC_ASSERT(cond) do { if (!(cond)) tl_counters.assert_failures++; } while (0)
@@ -885,7 +886,7 @@ struct SceneNode {                                                          // s
         V3 max_distance_point = transform_point(transform.inv_trans, ray_in.point_at_distance(max_distance));
         Ray ray = ray_in.transform(transform.inv_trans);
         max_distance = length(ray.origin - max_distance_point);
-        if (primitive && !(g_legacy_clear_shadows && material && material->fully_clear())) {
+        if (primitive && !(material && material->fully_clear())) {
             tl_counters.instance_tests++;
             if (auto it = primitive->get_closest_intersect(ray)) {
                 if (it->distance <= max_distance) return NodeIntersect{id, material.get(), it->transform(transform)};
@@ -980,7 +981,8 @@ struct TranslucentShader : Shadable {                                       // s
     Color translucency;
     double refractive_index;
     bool legacy = false;                                                    // RtShader.p[4]: the earlier revision, see get_color
-    bool fully_clear() const override { return translucency.r >= 1.0 && translucency.g >= 1.0 && translucency.b >= 1.0; }   // get_opacity == BLACK
+    bool clear_to_light = false;                                            // RtShader.p[5]: shadow tests pass through (an older revision still)
+    bool fully_clear() const override { return clear_to_light || (g_legacy_clear_shadows && translucency.r >= 1.0 && translucency.g >= 1.0 && translucency.b >= 1.0); }   // get_opacity == BLACK
     std::pair<double, double> get_fresnel(const Intersect& it) const {      // :19-46
         double cosi = dot(it.ray.direction, it.surface_normal);
         double etai = 1.0, etat = refractive_index;
@@ -1162,7 +1164,30 @@ struct SquareLight : Lightable {                                            // :
             subdivide_illumination(bot, right, scene, it, depth - 1, 4 * code + 3, out);
         }
     }
+    // Diagnostic (g_legacy_square_light): the sampling SquareLight still carries as dead code - get_sample's
+    // SAMPLE_RATE = 400 uniform points (:355-363) through the trait's default get_illums_at (:17-44), every one of them
+    // shadow-tested.  The area-light images of the reference's gallery predate subdivide_illumination; with this
+    // their penumbrae are reproduced (tools/penumbra_experiment.py).
+    std::vector<Illum> get_illums_uniform(const Scene& scene, const Intersect& it) const {
+        constexpr uint32_t SAMPLE_RATE = 400;                               // :186
+        std::vector<Illum> out;
+        out.reserve(SAMPLE_RATE);
+        for (uint32_t i = 0; i < SAMPLE_RATE; ++i) {
+            double u, v;
+            rng_light_pair(it.ray.stream, it.ray.path, index, 0x100000u + i, u, v);
+            V3 light_pos = position + v3(-size * 0.5 + size * u, 0.0, -size * 0.5 + size * v);
+            V3 hit_to_light = light_pos - it.hit_point;
+            V3 light_direction = normalize(hit_to_light);
+            double surface_dot = dot(light_direction, it.surface_normal);
+            if (surface_dot <= 0.0) { out.push_back({false}); continue; }
+            double light_distance = length(hit_to_light);
+            if (shadowed(scene, it, light_direction, light_distance)) out.push_back({false});
+            else out.push_back({true, surface_dot, light_direction, get_intensity(light_distance) / (double)SAMPLE_RATE});
+        }
+        return out;
+    }
     std::vector<Illum> get_illums_at(const Scene& scene, const Intersect& it) const override {   // :370-374
+        if (g_legacy_square_light) return get_illums_uniform(scene, it);
         double half_size = size * 0.5;
         std::vector<Illum> out;
         subdivide_illumination({-half_size, -half_size}, {half_size, half_size}, scene, it, SUB_DEPTH, 0, out);
@@ -1273,7 +1298,7 @@ static std::unique_ptr<Built> build(const RtSceneDesc& d) {
             case RT_SHADER_TEXTURE: { auto p = std::make_shared<TextureShader>(); p->image = b->images[s.ref].get(); out = p; break; }
             case RT_SHADER_REFLECTION: { auto p = std::make_shared<ReflectionShader>(); p->reflectivity = {s.p[0], s.p[1], s.p[2]}; out = p; break; }
             case RT_SHADER_TRANSLUCENT: {
-                auto p = std::make_shared<TranslucentShader>(); p->translucency = {s.p[0], s.p[1], s.p[2]}; p->refractive_index = s.p[3]; p->legacy = s.p[4] != 0.0; out = p; break;
+                auto p = std::make_shared<TranslucentShader>(); p->translucency = {s.p[0], s.p[1], s.p[2]}; p->refractive_index = s.p[3]; p->legacy = s.p[4] != 0.0; p->clear_to_light = s.p[5] != 0.0; out = p; break;
             }
             case RT_SHADER_MIX: {
                 auto p = std::make_shared<MixShader>();
@@ -1574,5 +1599,7 @@ void oracle_set_mesh_brute_force(int on) { orc::g_mesh_brute_force = on != 0; }
 // further difference that explains gallery/subtraction_room.png, rendered by a revision older still than the one
 // behind gallery/glass_monkey.png.  Used only to pin the oracle against that image.
 void oracle_set_legacy_clear_shadows(int on) { orc::g_legacy_clear_shadows = on != 0; }
+// Diagnostic: 1 = SquareLight as its dead code has it (400 uniform, shadow-tested samples, light.rs:355-363 + :17-44).
+void oracle_set_legacy_square_light(int on) { orc::g_legacy_square_light = on != 0; }
 
 }  // extern "C"

@@ -109,12 +109,12 @@ struct Workspace {
     DeviceBuf color, distance, hit_id, mask, list, samples, rows, scalars, rgb_full;
     DeviceBuf queue[2], acc, acc_flags, lane_mem;
     // queue-pipeline path: rays / shadow tests of two generations, their query records, walk list
-    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars;
+    DeviceBuf wf_rays[2], wf_shadows[2], wf_rjobs, wf_sjobs, wf_walk_list, wf_csg_list, wf_overflow, wf_scalars, wf_ties;
     uint32_t wf_cap = 0;
     bool acc_dirty = false;                        // a frame was abandoned between its rounds and its resolve
     std::vector<DeviceBuf*> all() {
         return {&color, &distance, &hit_id, &mask, &list, &samples, &rows, &scalars, &rgb_full, &queue[0], &queue[1], &acc, &acc_flags, &lane_mem,
-                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars};
+                &wf_rays[0], &wf_rays[1], &wf_shadows[0], &wf_shadows[1], &wf_rjobs, &wf_sjobs, &wf_walk_list, &wf_csg_list, &wf_overflow, &wf_scalars, &wf_ties};
     }
     void use(Arena* a) { for (DeviceBuf* b : all()) b->arena = a; }
     void release() { for (DeviceBuf* b : all()) b->release(); }
@@ -139,6 +139,7 @@ struct RtScene {
     // Shade kernel of the queue pipeline per hit list (materials without / with rays): 0 the general kernel, 1 / 2 the
     // kernel built for a class of simple materials (k_wf_shade in rt_wavefront.h), when every material on the list is of it
     int shade_cls[2] = {0, 0};
+    bool ties_possible = false;            // two or more instances of the kinds whose ties k_wf_ties decides
     uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
     bool last_used_queues = false, queue_overflowed = false;
     int last_attempts = 1;                 // frames the most recent synchronous call enqueued
@@ -247,6 +248,7 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
 #define UP(field, vec) if (rc == RT_OK) rc = upload(vec, s->owned, &d.field)
     UP(tlas_nodes, fs.tlas_nodes); UP(tlas_index, fs.tlas_index); UP(tlas_unbounded, fs.tlas_unbounded);
     UP(bvh_nodes, fs.bvh_nodes); UP(mesh_tris, fs.mesh_tris); UP(mesh_attrs, fs.mesh_attrs); UP(texels, fs.texels);
+    UP(node_xf, fs.node_xf); UP(inst_chain, fs.inst_chain); UP(chain_nodes, fs.chain_nodes);
 #undef UP
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
     if (fs.flip_on_device)
@@ -263,6 +265,14 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
     d.features = fs.features; d.max_ray_spawn = fs.max_ray_spawn; d.max_shadow_spawn = fs.max_shadow_spawn;
     d.inline_point_lights = fs.inline_point_lights;
+    {
+        uint32_t chainable = 0;
+        for (const DInstance& in : fs.instances) {
+            const DPrim& p = fs.prims[in.prim];
+            if (p.kind != DP_MESH && p.kind != DP_CSG && !p.wrap) ++chainable;
+        }
+        s->ties_possible = chainable >= 2;
+    }
     {   // (RT_WF_SHADE_CLS=0: every list on the general kernel, for tests that compare the two)
         const char* e = std::getenv("RT_WF_SHADE_CLS");
         const bool allow = !(e && std::atoi(e) == 0);
@@ -486,6 +496,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     const bool fixed_mem = w.color.arena != nullptr;
     const uint32_t walk_cus_max = fixed_mem ? std::min(128u, (uint32_t)s->num_cus) : (uint32_t)s->num_cus;
     const size_t walk_overflow_bytes = (size_t)(fixed_mem ? 1u : 4u) * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4u;   // per chain: a walk launch with up to 2048 threads per CU
+    // (the static scratch array also holds the tie lists: RT_WF_Q * RT_WF_TIE_WORDS words, within the slack below)
     const size_t wf_entry_bytes = 2 * (RQ_NF * 8 + RQ_NU * 4) + 2 * (SQ_NF * 8 + SQ_NU * 4) + 2 * (JQ_NF * 8 + JQ_NU * 4) +
                                   2 * sizeof(uint32_t) +
                                   ((s->ds.features & RTF_CSG) ? 2 * sizeof(uint32_t) : 0);
@@ -493,7 +504,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     uint32_t wf_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)W * num_rows * s->wf_scale, 1u << 20), WF_CAP_MAX);
     if (const char* ce = std::getenv("RT_WF_CAP")) { long v = std::atol(ce); if (v >= (long)RT_WF_Q) wf_cap = (uint32_t)std::min<long>(v, (long)WF_CAP_MAX); }   // tests: provoke an overflow
     if (fixed_mem) {
-        const size_t fixed = acc_slots * (RT_ACC_LIMBS * 8 + 4) + walk_overflow_bytes + WF_SCALAR_BYTES + 16 * 256;   // what is still to come, with alignment slack
+        const size_t fixed = acc_slots * (RT_ACC_LIMBS * 8 + 4) + walk_overflow_bytes + WF_SCALAR_BYTES + (size_t)RT_WF_Q * RT_WF_TIE_WORDS * 4 + 16 * 256;   // what is still to come, with alignment slack
         const size_t left = w.color.arena->capacity > w.color.arena->used + fixed ? w.color.arena->capacity - w.color.arena->used - fixed : 0;
         wf_cap = (uint32_t)std::min<size_t>(std::min<size_t>(left / wf_entry_bytes, (size_t)W * num_rows * 32), WF_CAP_MAX);
     }
@@ -591,6 +602,9 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         if ((e = w.wf_overflow.ensure(walk_overflow_bytes)) != RT_OK) return e;
         if ((e = w.wf_scalars.ensure(WF_SCALAR_BYTES)) != RT_OK) return e;
         HIP_TRY(hipMemsetAsync(w.wf_scalars.p, 0, WF_SCALAR_BYTES, stream));
+        if ((e = w.wf_ties.ensure((size_t)RT_WF_Q * RT_WF_TIE_WORDS * 4)) != RT_OK) return e;
+        HIP_TRY(hipMemsetAsync(w.wf_ties.p, 0, (size_t)RT_WF_Q * RT_WF_TIE_WORDS * 4, stream));
+        wa.tie_list = (uint32_t*)w.wf_ties.p;
         w.wf_cap = (uint32_t)n;
         auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
         wa.rjobs = queue(w.wf_rjobs, n, JQ_NF); wa.sjobs = queue(w.wf_sjobs, n, JQ_NF);
@@ -627,6 +641,8 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         HIP_TRY(hipGetLastError());
         uint32_t chains = fixed_mem ? 1u : wf_chains((size_t)W * num_rows);
         if (!fixed_mem) { const char* pe = std::getenv(mode == 0 ? "RT_WF_CHAINS_P0" : "RT_WF_CHAINS_P1"); if (pe) { long v = std::atol(pe); chains = v >= 4 ? 4u : (v >= 2 ? 2u : 1u); } }
+        const char* te = std::getenv("RT_WF_TIES");                    // (read per frame; 0: ties stay as the 8-ulp rule decided them, as on the persistent kernel)
+        const bool ties = s->ties_possible && !(te && std::atoi(te) == 0);
         uint32_t* const overflow0 = wa.walk_overflow;
         if (chains > 1) {                                             // the other chains start once generation 0 is in the queues
             HIP_TRY(hipEventRecord(s->chain_fork, stream));
@@ -653,6 +669,10 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                 const uint32_t cgrid = grid / chains;
                 int lrc = wf_launch(0, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                 if (lrc != RT_OK) return lrc;
+                if (ties) {                                              // surfaces that can meet at one distance: decide noted ties the reference's way
+                    lrc = wf_launch(6, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    if (lrc != RT_OK) return lrc;
+                }
                 if (s->ds.features & RTF_CSG) {                          // the queries that reach a composite shape
                     lrc = wf_launch(3, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                     if (lrc != RT_OK) return lrc;

@@ -160,7 +160,20 @@ struct DLight {
 
 struct DInstance {
     DXform x;
-    uint32_t prim, shader, node_id, is_root;
+    uint32_t prim, shader, node_id;
+    uint32_t is_root;          // bit 0: the scene's root node (its shadow test is inclusive, scene.rs:236); bit 1: shadow tests pass through (RT_INST_CLEAR_TO_LIGHT)
+};
+#define RT_INST_ROOT 1u
+#define RT_INST_CLEAR_TO_LIGHT 2u
+
+// The reference's own chain of transforms, node by node, for the rare query that has to be decided the way
+// SceneNode::trace decides it (two hits at distances that differ by rounding only): per scene node its matrix
+// and the inverse as DMat4::inverse computes it, per instance the nodes from the root down to its own.
+struct DNodeXf {
+    DAffine trans, inv;        // node -> parent, parent -> node
+};
+struct DChain {
+    uint32_t first, len;       // chain_nodes[first .. first + len): node indices, root first
 };
 
 // Per-lane working memory of the trace kernel (global memory, one contiguous block per lane so
@@ -198,6 +211,9 @@ struct alignas(16) TraceJob {  // one scene query of the current trip, between i
 
 struct DScene {
     const DInstance* instances;  uint32_t num_instances;
+    const DNodeXf* node_xf;          // per scene node (global memory: read by tie decisions only)
+    const DChain* inst_chain;        // per instance
+    const uint32_t* chain_nodes;
     const uint32_t* mesh_instances; uint32_t num_mesh_instances;   // instances whose primitive is an un-wrapped mesh, ascending
     const DBvhNode* tlas_nodes;      // BVH over the world-space boxes of the bounded instances (null: test every instance in turn)
     const uint32_t* tlas_index;      // leaf contents: instance indices

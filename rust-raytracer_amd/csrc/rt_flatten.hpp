@@ -78,6 +78,33 @@ inline Mat4 inverse(const Mat4& a) {   // Gauss-Jordan with partial pivoting
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out.m[c * 4 + r] = w[r][4 + c];
     return out;
 }
+// The inverse as the reference computes it (DMat4::inverse through cgmath: the adjugate - every cofactor a 3 x 3
+// determinant a(ei - fh) - b(di - fg) + c(dh - eg) - times 1 / det, the determinant expanded along the first row).
+// Used for the per-node chain of transforms that decides exact ties (DNodeXf): there the last bit matters.
+inline Mat4 inverse_by_cofactors(const Mat4& m) {
+    double a[4][4];
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) a[r][c] = m.m[c * 4 + r];
+    auto det3 = [](double p, double q, double r, double s, double t, double u, double v, double w, double x) {
+        return p * (t * x - u * w) - q * (s * x - u * v) + r * (s * w - t * v);
+    };
+    double cof[4][4];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double sub[9];
+            int n = 0;
+            for (int i = 0; i < 4; ++i) {
+                if (i == r) continue;
+                for (int j = 0; j < 4; ++j) if (j != c) sub[n++] = a[i][j];
+            }
+            const double d = det3(sub[0], sub[1], sub[2], sub[3], sub[4], sub[5], sub[6], sub[7], sub[8]);
+            cof[r][c] = ((r + c) & 1) ? -d : d;
+        }
+    const double det = a[0][0] * cof[0][0] + a[0][1] * cof[0][1] + a[0][2] * cof[0][2] + a[0][3] * cof[0][3];
+    const double inv_det = 1.0 / det;
+    Mat4 out;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out.m[c * 4 + r] = cof[c][r] * inv_det;
+    return out;
+}
 inline DAffine affine(const Mat4& a) {
     DAffine r;
     for (int row = 0; row < 3; ++row) for (int c = 0; c < 4; ++c) r.r[row * 4 + c] = a.m[c * 4 + row];
@@ -148,6 +175,9 @@ struct FlatScene {
     std::vector<DBvhNode> bvh_nodes;
     std::vector<DMeshTri> mesh_tris;
     std::vector<DMeshAttr> mesh_attrs;
+    std::vector<DNodeXf> node_xf;           // per scene node
+    std::vector<DChain> inst_chain;         // per instance
+    std::vector<uint32_t> chain_nodes;
     std::vector<DCsgRoot> csg_roots;
     std::vector<DCsgOp> csg_ops;
     std::vector<DCsgLeaf> csg_leaves;
@@ -640,12 +670,17 @@ private:
         if (fs_.tlas_nodes.empty()) { fs_.tlas_index.clear(); fs_.tlas_unbounded.clear(); }   // a single leaf: not worth it
     }
 
+    std::vector<uint32_t> path_;       // the nodes from the root to the one being walked
     void walk(uint32_t i, const Mat4& parent_l2w, const Mat4& parent_w2l) {
         if (i >= d_.num_nodes) throw Invalid("node index out of range");
         const RtNode& n = d_.nodes[i];
         Mat4 t = from_pod(n.trans);
         Mat4 l2w = mul(parent_l2w, t);
         Mat4 w2l = mul(inverse(t), parent_w2l);
+        if (fs_.node_xf.size() < d_.num_nodes) fs_.node_xf.resize(d_.num_nodes);
+        fs_.node_xf[i].trans = affine(t);
+        fs_.node_xf[i].inv = affine(inverse_by_cofactors(t));
+        path_.push_back(i);
         if (n.prim != RT_NONE) {
             DInstance inst{};
             inst.x = make_xform(l2w, w2l);
@@ -653,11 +688,18 @@ private:
             if (n.shader >= d_.num_shaders) throw Invalid("node shader out of range");
             inst.shader = n.shader;
             inst.node_id = i;
-            inst.is_root = i == 0;
+            inst.is_root = i == 0 ? RT_INST_ROOT : 0u;
+            // (an earlier revision of the reference let shadow rays through surfaces of opacity BLACK; RtShader.p[5] of a
+            // TranslucentShader asks for that, see rt_amd.h)
+            const RtShader& sh = d_.shaders[n.shader];
+            if (sh.kind == RT_SHADER_TRANSLUCENT && sh.p[5] != 0.0) inst.is_root |= RT_INST_CLEAR_TO_LIGHT;
             fs_.instances.push_back(inst);
+            fs_.inst_chain.push_back(DChain{(uint32_t)fs_.chain_nodes.size(), (uint32_t)path_.size()});
+            fs_.chain_nodes.insert(fs_.chain_nodes.end(), path_.begin(), path_.end());
         }
         if (n.subtree_size == 0 || i + n.subtree_size > d_.num_nodes) throw Invalid("bad subtree_size");
         for (uint32_t c = i + 1; c < i + n.subtree_size; c += d_.nodes[c].subtree_size) walk(c, l2w, w2l);
+        path_.pop_back();
     }
 
     uint32_t prim(uint32_t i) {

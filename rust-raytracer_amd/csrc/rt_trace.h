@@ -84,12 +84,15 @@ struct Work {            // per-thread work counters, compiled out when COUNT is
 // insertion order (src/scene.rs:200-217): of hits at equal distance the earlier node in DFS
 // pre-order wins.  It measures those distances after a chain of per-level transforms, the flat
 // instance loop after one composed transform, so surfaces that tie exactly there can differ by a
-// few units in the last place here (and the other way round): distances within 8 ulp count as
-// equal and go to the earlier instance.
+// few units in the last place here (and the other way round).  Hits that close are decided by
+// exact_tie_order below, the reference's own way; where that cannot be done (meshes, composite shapes,
+// wrapped primitives) distances within 8 ulp count as equal and go to the earlier instance.
+RT_DEV bool near_tie(double t, double best, double ulps) {
+    return fabs(t - best) <= ulps * 2.220446049250313e-16 * fmax(fabs(t), fabs(best));
+}
 RT_DEV bool replaces_hit(double t, uint32_t i, double best, uint32_t best_i, bool found) {
     if (!found) return t < best;
-    const double tol = 8.0 * 2.220446049250313e-16 * fmax(fabs(t), fabs(best));
-    if (fabs(t - best) <= tol) return i < best_i;
+    if (near_tie(t, best, 8.0)) return i < best_i;
     return t < best;
 }
 
@@ -557,10 +560,10 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                     RT_COUNT(wk, instance_tests);
                     inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
                     tmax = qt * s;
-                    inclusive = in.is_root != 0;
+                    inclusive = (in.is_root & RT_INST_ROOT) != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
-                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn)) {
+                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn) && !(any && (in.is_root & RT_INST_CLEAR_TO_LIGHT))) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
                         if (LDS) { s32 = slab32_setup(lr.o, inv, mesh.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
@@ -780,6 +783,7 @@ RT_DEV bool csg_closest(const DScene& sc, const DCsgRoot& root, const LRay& r, C
             double s, inv_s;
             LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
             Cand c[2];
+            RT_COUNT(wk, instance_tests);                              // (a leaf: ray into its space + primitive test, like a node's)
             int n = basic_hits<F, COUNT>(sc, p, lr, INFINITY, c, wk);
             if constexpr (F & RTF_WRAP) { if (p.wrap) n = wrap_all<F>(sc, p, lr, c, n); }
             lbegin[nl] = top; lcount[nl] = 0;
@@ -882,6 +886,7 @@ RT_DEV int csg_closest_fast(const DScene& sc, const DCsgRoot& root, const LRay& 
         double s, inv_s;
         LRay lr = to_local(leaf.x, r.o, r.d, s, inv_s);
         Cand c[2];
+        RT_COUNT(wk, instance_tests);                                  // (a leaf: ray into its space + primitive test, like a node's)
         int n = basic_hits<F, COUNT>(sc, p, lr, INFINITY, c, wk);
         if constexpr (F & RTF_WRAP) { if (p.wrap) n = wrap_all<F>(sc, p, lr, c, n); }
         double t0 = INFINITY, t1 = INFINITY;
@@ -950,6 +955,78 @@ RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details&
     o.u = d.u; o.v = d.v;
 }
 
+// ------------------------------------------------------------------ exact ties (src/scene.rs:196-225)
+// The distance SceneNode::trace compares for the closest hit of instance `i`, at depth `level` of the instance's
+// path of nodes: the ray goes down through every node's inverse transform and is renormalised at each
+// (geometry/ray.rs:90-97), the primitive is intersected in its own space, and the hit comes back up with its
+// distance measured again at every level between the transformed hit point and the transformed origin
+// (geometry/intersect.rs:31-45).  `level` is the node at which the comparison takes place: the instance's own
+// node (the primitive's own distance) or an ancestor of it.  False when the primitive is of a kind this does
+// not cover (meshes, composite shapes, wrapped primitives), or is not hit by the ray that went down the chain.
+template <uint32_t F>
+RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t level, double& dist) {
+    const DChain ch = sc.inst_chain[i];
+    const DPrim& p = sc.prims[sc.instances[i].prim];
+    if (p.kind == DP_MESH || p.kind == DP_CSG || ((F & RTF_WRAP) && p.wrap)) return false;
+    LRay r;
+    r.o = o; r.d = d;
+    for (uint32_t k = 0; k < ch.len; ++k) {
+        const DNodeXf& x = sc.node_xf[sc.chain_nodes[ch.first + k]];
+        r.o = xf_point(x.inv, r.o);
+        r.d = normalize(xf_vector(x.inv, r.d));
+    }
+    Cand c[2];
+    Work<false> none;
+    if (basic_hits<F, false>(sc, p, r, INFINITY, c, none) == 0) return false;
+    dist = c[0].t;
+    d3 hit = r.o + (c[0].t * r.d), org = r.o;
+    if constexpr (F & RTF_FACED) {
+        if (p.kind == DP_FACED) {                                  // a cube's hit point comes back through its face's matrix (cube.rs:44-47)
+            Details dt;
+            faced_details(sc, sc.faced[p.ref], r, c[0].a, dt);
+            hit = dt.p;
+        }
+    }
+    for (uint32_t k = ch.len - 1u; k > level; --k) {
+        const DNodeXf& x = sc.node_xf[sc.chain_nodes[ch.first + k]];
+        hit = xf_point(x.trans, hit);
+        org = xf_point(x.trans, org);
+        dist = length(hit - org);
+    }
+    return true;
+}
+// Two hits whose distances differ by rounding only, on instances `i` (the one being tested) and `j` (the best so
+// far): 1 when the reference would keep i's, 0 when j's, -1 when this cannot tell.  The reference compares them at
+// their lowest common ancestor, strictly: the later one (DFS pre-order = instance order) wins only when nearer.
+template <uint32_t F>
+RT_DEV int exact_tie_order(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j) {
+    const DChain a = sc.inst_chain[i], b = sc.inst_chain[j];
+    uint32_t common = 0;
+    while (common < a.len && common < b.len && sc.chain_nodes[a.first + common] == sc.chain_nodes[b.first + common]) ++common;
+    if (common == 0) return -1;
+    double di = 0.0, dj = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {                                  // (one copy of the code for both: this path is rare, its registers are not)
+        double dk;
+        if (!chain_distance<F>(sc, o, d, k ? j : i, common - 1u, dk)) return -1;
+        if (k) dj = dk; else di = dk;
+    }
+    return i > j ? (di < dj ? 1 : 0) : (dj < di ? 0 : 1);
+}
+
+// A workgroup's list of such decisions, in LDS: (query, instance tested, best instance at that moment).  A full list
+// drops further notes (their decisions stand as the 8-ulp rule made them).
+#define RT_TIE_LIST 48u
+struct TieLog {
+    uint32_t* count;           // LDS: entries noted so far
+    uint32_t* entries;         // LDS: RT_TIE_LIST x 3 words
+    uint32_t query;            // the query the calling lane is working on
+    RT_DEV void note(uint32_t i, uint32_t j) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < RT_TIE_LIST) { entries[3 * at] = query; entries[3 * at + 1] = i; entries[3 * at + 2] = j; }
+    }
+};
+
 // ------------------------------------------------------------------ scene queries
 struct SceneHit {
     double t;            // world distance
@@ -966,6 +1043,7 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
             const DCsgRoot& root = sc.csg_roots[p.ref];
             if (root.bounded) {                                       // most rays pass the composite by: no leaf to hit, no lists to merge
                 double tn;
+                RT_COUNT(wk, box_tests);
                 if (!slab(root.lo, root.hi, lr.o, mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z), INFINITY, tn)) return false;
             }
             if constexpr (WITH_CSG) {
@@ -998,8 +1076,10 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
 // Scenes with many instances carry a BVH over the instances' world-space boxes (RTF_TLAS); the
 // reference tests every child of a node in turn (src/scene.rs:205-217), which only fixes the
 // winner among equal distances: the earlier instance, kept here by an explicit tie rule.
-template <uint32_t F, bool COUNT, bool SKIP_MESH, bool WITH_CSG = true>
-RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk, uint32_t* deferred = nullptr) {
+// `ties` (optional): closest-hit decisions between two instances whose distances differ by rounding only are noted
+// there (TieLog), for the caller to decide again the reference's way once the query is through.
+template <uint32_t F, bool COUNT, bool SKIP_MESH, bool WITH_CSG = true, class TIES = TieLog>
+RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk, uint32_t* deferred = nullptr, TIES* ties = nullptr) {
     bool found = false;
     double best = any ? max_distance : INFINITY;
     // one instance; returns true when an any-hit query is settled
@@ -1007,6 +1087,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
         if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) return false; }
+        if (any && (in.is_root & RT_INST_CLEAR_TO_LIGHT)) return false;   // (an earlier revision's shadow test, see DInstance)
         RT_COUNT(wk, instance_tests);
         if (p.kind == DP_RECTANGLE && !((F & RTF_WRAP) && p.wrap)) {
             // A rectangle lies in its frame's z = 0 plane, and the ray meets that plane at -o.z / d.z (rect_hit): the
@@ -1029,15 +1110,16 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
             if constexpr ((F & RTF_MESH) && !SKIP_MESH) {
                 // one call site for both query kinds: shadow lanes and camera/secondary lanes walk together
                 c.b = 0;
-                got = mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], lr, any, best * s, in.is_root != 0, c.t, c.a, wk);
+                got = mesh_walk<(F & RTF_LDS_BVH) != 0, COUNT>(sc, sc.meshes[p.ref], lr, any, best * s, (in.is_root & RT_INST_ROOT) != 0, c.t, c.a, wk);
                 if (any) return got;
             }
         } else {
             got = prim_closest<F, COUNT, WITH_CSG>(sc, p, lr, any ? INFINITY : best * s, c, wk, deferred);
-            if (any) return got && (in.is_root ? c.t <= max_distance * s : c.t < max_distance * s);
+            if (any) return got && ((in.is_root & RT_INST_ROOT) ? c.t <= max_distance * s : c.t < max_distance * s);
         }
         if (!got) return false;
         double tw = c.t * inv_s;
+        if (ties && found && near_tie(tw, best, 64.0)) ties->note(i, hit.inst);   // (rare: two surfaces at one distance; looked at again by resolve_tie)
         if (replaces_hit(tw, i, best, hit.inst, found)) { best = tw; hit.inst = i; hit.c = c; found = true; }
         return false;
     };
@@ -1093,6 +1175,28 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
     }
     hit.t = best;
     return found;
+}
+
+// One noted decision, looked at again: instances i (tested later in the loop) and j met at distances that differ by
+// rounding only.  `hit` is the query's answer as the loop left it.  When the reference's own comparison
+// (exact_tie_order) ranks the two the other way than the loop did, and one of them is the answer, the answer
+// changes hands; returns whether it did.
+template <uint32_t F>
+RT_DEV bool resolve_tie(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j, SceneHit& hit) {
+    if (hit.inst != i && hit.inst != j) return false;              // a nearer surface was found afterwards
+    const int exact = exact_tie_order<F>(sc, o, d, i, j);
+    if (exact < 0) return false;
+    const uint32_t want = exact ? i : j;
+    if (hit.inst == want) return false;
+    const DInstance& in = sc.instances[want];                      // its hit as the loop saw it
+    double s, inv_s;
+    const LRay lr = to_local(in.x, o, d, s, inv_s);
+    Work<false> none;
+    uint32_t unused = 0;
+    Cand c;
+    if (!prim_closest<F, false, false>(sc, sc.prims[in.prim], lr, INFINITY, c, none, &unused)) return false;
+    hit.inst = want; hit.c = c; hit.t = c.t * inv_s;
+    return true;
 }
 
 // Rebuild the world-space Intersect of the winning hit (geometry/intersect.rs:31-45 applied

@@ -60,7 +60,8 @@ inline hipError_t rt_grant_lds(const void* fn, uint32_t lds) {
 RT_TRACE_VARIANTS(RT_DECLARE_TRACE)
 #undef RT_DECLARE_TRACE
 // which: 0 analytic, 1 shade, 2 settle, 3 analytic redo (scenes with composite shapes), 4 / 5 shade on the kernel for
-// material class 1 / 2 (k_wf_shade; only built for scenes whose tables fit LDS, else the general kernel runs)
+// material class 1 / 2 (k_wf_shade; only built for scenes whose tables fit LDS, else the general kernel runs), 6 the tie
+// decisions noted by the analytic kernel (k_wf_ties; `grid` is ignored: one workgroup per sub-queue of the launch)
 #define RT_DECLARE_WF(name, F) \
     LaunchStatus rt_launch_wf_##name(int which, bool count, uint32_t grid, hipStream_t stream, const DScene& ds, const DRenderParams& rp, const WfArgs& wa);
 RT_WF_VARIANTS(RT_DECLARE_WF)
@@ -117,6 +118,11 @@ LaunchStatus launch_wf_variant(int which, bool count, uint32_t grid, hipStream_t
         if (which == 3)
             fn = hot ? (count ? (const void*)k_wf_analytic<F, true, true, true> : (const void*)k_wf_analytic<F, false, true, true>)
                      : (count ? (const void*)k_wf_analytic<F, true, false, true> : (const void*)k_wf_analytic<F, false, false, true>);
+    }
+    if (which == 6) {                                                    // the tie decisions the analytic kernel noted: one small workgroup per sub-queue
+        void* tie_params[3] = {(void*)&ds, (void*)&rp, (void*)&wa};
+        (void)hipLaunchKernel((const void*)k_wf_ties<F>, dim3(wa.sq_count), dim3(64), tie_params, 0, stream);
+        return {hipGetLastError(), "k_wf_ties launch"};
     }
     if (!fn) return {hipErrorInvalidValue, "queue-pipeline kernel selection"};
     (void)rt_grant_lds(fn, lds);

@@ -32,6 +32,7 @@ struct WalkInst {
     double lo[3], hi[3];
     double max_abs;
     uint32_t node_off, tri_off, lds_node_off, lds_tri_off, inst, is_root;
+    uint32_t kind, _pad;       // hit list of the instance's material: 1 without rays, 2 with (JQ_FOUND)
 };
 #define RT_WF_WALK_TABLE 8u
 #define RT_WF_WALK_FIXED_BYTES(threads) ((threads) * RT_WF_LDS_STACK * 4u + 2048u + RT_WF_WALK_TABLE * (uint32_t)sizeof(WalkInst))   // k_wf_walk's LDS apart from the BVH blob: walk stacks, list starts, instance table
@@ -46,6 +47,7 @@ RT_DEV WalkInst walk_inst(const DScene& sc, uint32_t m) {
     w.max_abs = mesh.max_abs;
     w.node_off = mesh.node_off; w.tri_off = mesh.tri_off; w.lds_node_off = mesh.lds_node_off; w.lds_tri_off = mesh.lds_tri_off;
     w.is_root = in.is_root;
+    w.kind = (sc.shader_bounds[in.shader] & 0xFFFFu) ? 2u : 1u; w._pad = 0u;
     return w;
 }
 // Every queue is cut into RT_WF_Q sub-queues with a fill counter each.  Appending costs one
@@ -70,7 +72,8 @@ struct WfQueue {
 enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH = 1, RQ_SLOT = 2, RQ_FLAGS = 3, RQ_NU = 4 };
 // shadow tests (ShadowJob): 10 doubles, 1 word
 enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
-// query records (TraceJob): 2 doubles, 5 words
+// query records (TraceJob): 2 doubles, 5 words.  JQ_FOUND: bit 0 a hit exists (any-hit: an occluder), bits 1-2 the hit list
+// its material belongs on (1: spawns no rays, 2: does), so that k_wf_settle need not follow instance -> shader -> bounds
 enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
 
 struct WfArgs {
@@ -117,6 +120,7 @@ struct WfArgs {
     const unsigned int* aa_count;
     uint32_t mode;
     uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
+    uint32_t* tie_list;               // per sub-queue RT_WF_TIE_WORDS words (k_wf_analytic -> k_wf_ties), all counts zero between launches
     uint32_t shade_lists;             // k_wf_shade: the hit lists this launch works on (bit 0: materials without rays, bit 1: the others)
     uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
 };
@@ -289,7 +293,8 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 // and differs from composite to composite (four spheres, a cube and a sphere, ...): listed side by
 // side, queries with the same work fill whole waves, and the first run keeps neither its registers
 // nor its scratch memory.
-// LDS: [small scene tables]
+// LDS: [small scene tables][sky-box scenes: per wave 64 x 10 words of staging, per wave 128 list entries]
+#define RT_WF_TIE_WORDS (4u + RT_TIE_LIST * 3u)   // a sub-queue's list of noted tie decisions: count, then (query, instance, instance) triples
 template <uint32_t F, bool COUNT, bool HOT, bool REDO>
 __global__ void __launch_bounds__(256)
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
@@ -307,6 +312,10 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     Work<COUNT> wk = {};
     unsigned long long cam = 0;
     const uint32_t* clist = a.csg_list + (size_t)sq * (2u * a.sub);
+    // Closest-hit decisions between two surfaces at (all but) one distance are noted in the sub-queue's tie list and
+    // decided again, the reference's way, by k_wf_ties (doing that here would cost this kernel its fifth wave per SIMD).
+    uint32_t* const tie_count = a.tie_list + (size_t)sq * RT_WF_TIE_WORDS;
+    uint32_t* const tie_entries = tie_count + 4;
     // One query (the body of the loop below).  Returns the entry of a ray that failed the gate of Scene::cast_ray in a
     // sky-box scene (what it sees is looked up afterwards), else RT_NO_SLOT.
     auto one_query = [&](uint32_t wi) -> uint32_t {
@@ -355,7 +364,9 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         SceneHit h;
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         uint32_t deferred = 0;
-        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred);
+        TieLog ties;
+        ties.count = tie_count; ties.entries = tie_entries; ties.query = q;
+        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred, (REDO || shadow) ? nullptr : &ties);
         if constexpr (HAS_CSG && !REDO) {
             if (deferred && !(shadow && found)) {                     // (an occluded shadow test needs no composite any more)
                 wk = wk_before; cam = cam_before;                     // its record is written, and its work counted, by the second run
@@ -367,7 +378,7 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
             }
         }
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
-        jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
+        jobs.U(cap, JQ_FOUND, q) = !found ? 0u : shadow ? 1u : 1u | (((sc.shader_bounds[sc.instances[h.inst].shader] & 0xFFFFu) ? 2u : 1u) << 1);
         jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
         if (!shadow) {                                                // (of a shadow test only the verdict is kept)
             jobs.F(cap, JQ_T, q) = h.t;
@@ -437,6 +448,41 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     }
     if (sky) look_up_sky(true);
     wf_flush<COUNT>(a.counters, wk, cam, a.mode);
+}
+
+// ------------------------------------------------------------------ exact ties
+// One 64-thread workgroup per sub-queue, right after the analytic kernel: the decisions it noted (none at all in
+// most launches: the workgroup leaves at once).  A query's notes are taken in the order in which they were made, by
+// the thread that holds the first of them; its record is rewritten if the answer changes hands.
+template <uint32_t F>
+__global__ void __launch_bounds__(64)
+k_wf_ties(DScene sc, DRenderParams rp, WfArgs a) {
+    const uint32_t sq = a.sq_base + blockIdx.x;
+    uint32_t* const tie_count = a.tie_list + (size_t)sq * RT_WF_TIE_WORDS;
+    const uint32_t* const tie_entries = tie_count + 4;
+    const uint32_t nt = min(*tie_count, RT_TIE_LIST);
+    if (nt == 0u) return;
+    const uint32_t cap = a.cap;
+    for (uint32_t e = threadIdx.x; e < nt; e += blockDim.x) {
+        const uint32_t q = tie_entries[3 * e];
+        bool first = true;
+        for (uint32_t k = 0; k < e; ++k) first = first && tie_entries[3 * k] != q;
+        if (!first || !(a.rjobs.U(cap, JQ_FOUND, q) & 1u)) continue;
+        const d3 o = a.rays.ld3(cap, RQ_O, q), d = a.rays.ld3(cap, RQ_D, q);
+        SceneHit h;
+        h.t = a.rjobs.F(cap, JQ_T, q); h.inst = a.rjobs.U(cap, JQ_INST, q);
+        h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
+        bool changed = false;
+        for (uint32_t k = e; k < nt; ++k)
+            if (tie_entries[3 * k] == q) changed = resolve_tie<F>(sc, o, d, tie_entries[3 * k + 1], tie_entries[3 * k + 2], h) || changed;
+        if (changed) {
+            a.rjobs.F(cap, JQ_T, q) = h.t; a.rjobs.F(cap, JQ_CT, q) = h.c.t;
+            a.rjobs.U(cap, JQ_INST, q) = h.inst; a.rjobs.U(cap, JQ_CA, q) = h.c.a; a.rjobs.U(cap, JQ_CB, q) = h.c.b;
+            a.rjobs.U(cap, JQ_FOUND, q) = 1u | (((sc.shader_bounds[sc.instances[h.inst].shader] & 0xFFFFu) ? 2u : 1u) << 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *tie_count = 0u;                            // (the list is the next generation's again)
 }
 
 // ------------------------------------------------------------------ mesh walk
@@ -530,11 +576,14 @@ k_wf_walk(DScene sc, WfArgs a) {
     auto finish_query = [&]() {
         if (qchanged) {                                               // (else the analytic phase's record stands)
             const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
-            jobs.U(a.cap, JQ_FOUND, qe) = 1u;
-            if (!qshadow) {                                           // (of a shadow test only the verdict is read)
+            if (qshadow) jobs.U(a.cap, JQ_FOUND, qe) = 1u;            // (of a shadow test only the verdict is read)
+            else {
+                const uint32_t mi = qca >> 28;                        // the winning mesh instance's place in the table (7: or beyond it)
+                const uint32_t kind = mi < RT_WF_WALK_TABLE - 1u ? wtable[mi].kind : ((sc.shader_bounds[sc.instances[qinst].shader] & 0xFFFFu) ? 2u : 1u);
+                jobs.U(a.cap, JQ_FOUND, qe) = 1u | (kind << 1);
                 jobs.F(a.cap, JQ_T, qe) = qt; jobs.F(a.cap, JQ_CT, qe) = qct;
                 jobs.U(a.cap, JQ_INST, qe) = qinst;
-                jobs.U(a.cap, JQ_CA, qe) = qca; jobs.U(a.cap, JQ_CB, qe) = 0u;
+                jobs.U(a.cap, JQ_CA, qe) = qca & 0x0FFFFFFFu; jobs.U(a.cap, JQ_CB, qe) = 0u;
             }
         }
         have = false;
@@ -605,10 +654,10 @@ k_wf_walk(DScene sc, WfArgs a) {
                     RT_COUNT(wk, instance_tests);
                     inv = mk3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
                     tmax = qt * s;
-                    inclusive = wi.is_root != 0;
+                    inclusive = (wi.is_root & RT_INST_ROOT) != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
-                    if (slab(wi.lo, wi.hi, lr.o, inv, tmax, tn)) {
+                    if (slab(wi.lo, wi.hi, lr.o, inv, tmax, tn) && !(qshadow && (wi.is_root & RT_INST_CLEAR_TO_LIGHT))) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
                         if (LDS) { s32 = slab32_setup(lr.o, inv, wi.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + wi.node_off; gtris = sc.mesh_tris + wi.tri_off;
@@ -693,7 +742,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                         double tw = best * inv_s;
                         if (replaces_hit(tw, inst, qt, qinst, qfound != 0u)) {
                             qt = tw; qinst = inst; qfound = 1u; qchanged = true;
-                            qct = best; qca = tri;
+                            qct = best; qca = tri | (min(m, 7u) << 28);   // (with the mesh instance's place in the table: finish_query looks its material's list up there)
                         }
                     }
                 }
@@ -830,7 +879,8 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
                     RT_COUNT(wk, shade_evals);
                 }
             } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
-                if (!a.rjobs.U(cap, JQ_FOUND, q)) {
+                const uint32_t fw = a.rjobs.U(cap, JQ_FOUND, q);
+                if (!(fw & 1u)) {
                     if (batch_misses) missed = true;
                     else {
                         cslot = a.rays.U(cap, RQ_SLOT, q);
@@ -838,8 +888,7 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
                         if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
                     }
                 } else {
-                    const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
-                    kind = (bounds & 0xFFFFu) ? 2u : 1u;
+                    kind = fw >> 1;
                 }
             }
         }

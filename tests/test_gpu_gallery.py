@@ -87,3 +87,45 @@ def test_area_light_scenes_agree_with_the_reference_images_in_block_means(name, 
         ((d <= 1.0).mean(), (d <= 3.0).mean(), (d <= 8.0).mean())
     assert np.abs(r["rgb"].reshape(-1, 3).mean(axis=0) - gold.reshape(-1, 3).astype(float).mean(axis=0)).max() < 0.6
     assert np.corrcoef(blocks(r["rgb"]).ravel(), blocks(gold).ravel())[0, 1] > 0.999
+
+
+# subtraction_room.png (5000 x 5000) is older still: ceiling and floor colours the other way round, the same one-ray
+# TranslucentShader (RtShader.p[4]), and shadow tests that pass through surfaces of opacity BLACK (RtShader.p[5]).
+# With those every pixel outside the AA mask is deterministic: the walls, and the two composite solids (three
+# nested subtractions over four spheres; a cube minus a sphere) with everything seen through them.
+def legacy_subtraction_room(scenes_mod, abi_mod):
+    s = scenes_mod.Scene("subtraction_room")
+    d = C.cast(s.desc, C.POINTER(abi_mod.RtSceneDesc)).contents
+    ceiling, floor = d.shaders[d.nodes[2].shader], d.shaders[d.nodes[3].shader]
+    for k in range(10):
+        ceiling.p[k], floor.p[k] = floor.p[k], ceiling.p[k]
+    for node in (8, 9):
+        clear = d.shaders[d.nodes[node].shader]
+        assert clear.kind == 3
+        clear.p[4] = 1.0
+        clear.p[5] = 1.0
+    return s
+
+
+def test_composite_shapes_equal_the_reference_image_on_every_deterministic_pixel(scenes_mod, abi_mod, render_mod):
+    Image.MAX_IMAGE_PIXELS = None
+    gold = gallery("subtraction_room")
+    assert gold.shape == (5000, 5000, 3)
+    s = legacy_subtraction_room(scenes_mod, abi_mod)
+    dim, cam, cfg = s.view(width=5000, height=5000, anti_alias=True, seed=1)
+    ds = render_mod.DeviceScene(s, device=0)
+    r = ds.render(dim, cam, cfg, count_work=True)
+    ds.close()
+    assert r["counters"]["stack_overflows"] == 0 and r["counters"]["csg_events"] > 0
+    det = r["aa_mask"] == 0
+    diff = np.abs(r["rgb"].astype(int) - gold.astype(int)).max(axis=2)
+    solids = det & ((r["hit_id"] == 8) | (r["hit_id"] == 9))
+    walls = det & ~solids
+    assert walls.sum() > 19000000 and solids.sum() > 3000000
+    assert diff[walls].max() == 0, f"{(diff[walls] > 0).sum()} wall pixels differ from the reference image"
+    # (what differs - 0.07 % of the composite pixels - lies on curves one pixel wide on the spiked solid, where the
+    # surfaces of two of its spheres cross and two events of the interval walk coincide; every such pixel touches the AA mask)
+    assert (diff[solids] > 0).sum() <= solids.sum() // 1000, f"{(diff[solids] > 0).sum()} of {solids.sum()} composite pixels differ"
+    # (the re-sampled pixels carry that revision's own jitter - and, it seems, sample pattern: 3.4 LSB brighter on average)
+    aa = ~det
+    assert abs(r["rgb"][aa].astype(float).mean() - gold[aa].astype(float).mean()) < 5.0
