@@ -265,6 +265,8 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     d.has_background = fs.has_background; d.background_image = fs.background_image; d.background_w2l = fs.background_w2l;
     d.features = fs.features; d.max_ray_spawn = fs.max_ray_spawn; d.max_shadow_spawn = fs.max_shadow_spawn;
     d.inline_point_lights = fs.inline_point_lights;
+    d.has_clear_to_light = 0;
+    for (const DInstance& in : fs.instances) if (in.is_root & RT_INST_CLEAR_TO_LIGHT) d.has_clear_to_light = 1;
     {
         uint32_t chainable = 0;
         for (const DInstance& in : fs.instances) {

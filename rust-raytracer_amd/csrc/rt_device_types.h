@@ -257,6 +257,7 @@ struct DScene {
     uint32_t max_ray_spawn;      // most secondary rays one hit can push
     uint32_t max_shadow_spawn;   // most deferred shadow tests one hit can push
     uint32_t inline_point_lights; // 1: point-light shadow tests run inside Phong (needs RTF_INLINE_LIGHTS)
+    uint32_t has_clear_to_light;  // 1: some instance carries RT_INST_CLEAR_TO_LIGHT
 };
 
 struct DCamera {

@@ -635,10 +635,15 @@ __global__ void __launch_bounds__(256) k_parse_lines(ObjArgs a) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.nlines) return;
     const uint8_t k = a.kind[l];
-    if (k == L_OTHER || k == L_OG) return;
+    if (k == L_OG) return;
     uint32_t p = a.starts[l];
     const uint32_t end = l + 1 < a.nlines ? a.starts[l + 1] : a.n;
     while (p < end && is_blank(a.text[p])) ++p;
+    if (k == L_OTHER) {   // point and line elements go through the reference parser's face path and add vertices: not read here
+        const char c0 = p < end ? a.text[p] : '\n', c1 = p + 1 < end ? a.text[p + 1] : '\n';
+        if ((c0 == 'l' || c0 == 'p') && (is_blank(c1) || c1 == '\n')) atomicOr(a.error, 2u);
+        return;
+    }
     p += (k == L_V || k == L_F) ? 1u : 2u;
     if (k == L_V || k == L_VT || k == L_VN) {
         const uint32_t comps = k == L_VT ? 2u : 3u;
@@ -650,6 +655,7 @@ __global__ void __launch_bounds__(256) k_parse_lines(ObjArgs a) {
             bool unsure = false;
             float f = 0.0f;
             if (p < end && a.text[p] != '\n') f = parse_f32(a.text, p, end, unsure);
+            else atomicOr(a.error, 2u);        // fewer components than the reference's parser insists on: it fails the load
             pool[comps * at + c] = f;
             if (unsure) note_unsure(a, k, comps * at + c, tok);
         }
@@ -819,6 +825,7 @@ int obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out) {
         uint32_t sc[2];
         ING_HIP(hipMemcpyAsync(sc, scalars, 8, hipMemcpyDeviceToHost, st));
         ING_HIP(hipStreamSynchronize(st));
+        if (sc[1] & 2u) return ing_fail(RT_ERR_UNSUPPORTED, "rt_obj_parse: a point or line element, or a v / vt / vn line with too few components");
         if (sc[1]) return ing_fail(RT_ERR_INVALID_ARG, "rt_obj_parse: a face names a vertex, texture coordinate or normal the text does not hold");
         if (sc[0] > a.unsure_cap) return ing_fail(RT_ERR_UNSUPPORTED, "rt_obj_parse: too many literals outside the device parser's range");
         if (sc[0]) {   // literals the device would not decide: the host's strtof rounds them once, like the reference's parser
@@ -830,7 +837,11 @@ int obj_parse(int device, const char* text, uint64_t bytes, RtObjMesh* out) {
                 uint32_t len = 0;
                 while (off + len < n && len < 63 && text[off + len] != ' ' && text[off + len] != '\t' && text[off + len] != '\r' && text[off + len] != '\n') { tok[len] = text[off + len]; ++len; }
                 tok[len] = 0;
-                const float f = std::strtof(tok, nullptr);
+                char* stop = nullptr;
+                const float f = std::strtof(tok, &stop);
+                // (Rust's f32 parser takes the whole token or fails the load; strtof would stop early or read hex)
+                if (len == 0 || stop != tok + len || std::strpbrk(tok, "xXpP"))
+                    return ing_fail(RT_ERR_UNSUPPORTED, std::string("rt_obj_parse: '") + tok + "' is no decimal number");
                 float* dst = (u[3 * i] == L_V ? a.v : u[3 * i] == L_VT ? a.vt : a.vn) + u[3 * i + 1];
                 ING_HIP(hipMemcpy(dst, &f, 4, hipMemcpyHostToDevice));
             }

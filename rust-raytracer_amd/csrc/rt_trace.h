@@ -563,7 +563,7 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
                     inclusive = (in.is_root & RT_INST_ROOT) != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
-                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn) && !(any && (in.is_root & RT_INST_CLEAR_TO_LIGHT))) {
+                    if (slab(mesh.lo, mesh.hi, lr.o, inv, tmax, tn) && !(sc.has_clear_to_light && any && (in.is_root & RT_INST_CLEAR_TO_LIGHT))) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
                         if (LDS) { s32 = slab32_setup(lr.o, inv, mesh.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + mesh.node_off; gtris = sc.mesh_tris + mesh.tri_off;
@@ -1087,7 +1087,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
         if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) return false; }
-        if (any && (in.is_root & RT_INST_CLEAR_TO_LIGHT)) return false;   // (an earlier revision's shadow test, see DInstance)
+        if (sc.has_clear_to_light && any && (in.is_root & RT_INST_CLEAR_TO_LIGHT)) return false;   // (an earlier revision's shadow test, see DInstance; the scene-wide flag keeps the table read out of every other scene's loop)
         RT_COUNT(wk, instance_tests);
         if (p.kind == DP_RECTANGLE && !((F & RTF_WRAP) && p.wrap)) {
             // A rectangle lies in its frame's z = 0 plane, and the ray meets that plane at -o.z / d.z (rect_hit): the
@@ -1119,7 +1119,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         }
         if (!got) return false;
         double tw = c.t * inv_s;
-        if (ties && found && near_tie(tw, best, 64.0)) ties->note(i, hit.inst);   // (rare: two surfaces at one distance; looked at again by resolve_tie)
+        if (ties && ties->count && found && near_tie(tw, best, 64.0)) ties->note(i, hit.inst);   // (rare: two surfaces at one distance; looked at again by resolve_tie)
         if (replaces_hit(tw, i, best, hit.inst, found)) { best = tw; hit.inst = i; hit.c = c; found = true; }
         return false;
     };

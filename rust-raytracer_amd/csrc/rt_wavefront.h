@@ -32,7 +32,6 @@ struct WalkInst {
     double lo[3], hi[3];
     double max_abs;
     uint32_t node_off, tri_off, lds_node_off, lds_tri_off, inst, is_root;
-    uint32_t kind, _pad;       // hit list of the instance's material: 1 without rays, 2 with (JQ_FOUND)
 };
 #define RT_WF_WALK_TABLE 8u
 #define RT_WF_WALK_FIXED_BYTES(threads) ((threads) * RT_WF_LDS_STACK * 4u + 2048u + RT_WF_WALK_TABLE * (uint32_t)sizeof(WalkInst))   // k_wf_walk's LDS apart from the BVH blob: walk stacks, list starts, instance table
@@ -47,7 +46,6 @@ RT_DEV WalkInst walk_inst(const DScene& sc, uint32_t m) {
     w.max_abs = mesh.max_abs;
     w.node_off = mesh.node_off; w.tri_off = mesh.tri_off; w.lds_node_off = mesh.lds_node_off; w.lds_tri_off = mesh.lds_tri_off;
     w.is_root = in.is_root;
-    w.kind = (sc.shader_bounds[in.shader] & 0xFFFFu) ? 2u : 1u; w._pad = 0u;
     return w;
 }
 // Every queue is cut into RT_WF_Q sub-queues with a fill counter each.  Appending costs one
@@ -72,8 +70,7 @@ struct WfQueue {
 enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH = 1, RQ_SLOT = 2, RQ_FLAGS = 3, RQ_NU = 4 };
 // shadow tests (ShadowJob): 10 doubles, 1 word
 enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
-// query records (TraceJob): 2 doubles, 5 words.  JQ_FOUND: bit 0 a hit exists (any-hit: an occluder), bits 1-2 the hit list
-// its material belongs on (1: spawns no rays, 2: does), so that k_wf_settle need not follow instance -> shader -> bounds
+// query records (TraceJob): 2 doubles, 5 words
 enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
 
 struct WfArgs {
@@ -364,9 +361,9 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         SceneHit h;
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         uint32_t deferred = 0;
-        TieLog ties;
-        ties.count = tie_count; ties.entries = tie_entries; ties.query = q;
-        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred, (REDO || shadow) ? nullptr : &ties);
+        TieLog ties;                                                  // (a null list: nothing is noted - shadow tests, the second run)
+        ties.count = (REDO || shadow) ? nullptr : tie_count; ties.entries = tie_entries; ties.query = q;
+        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred, &ties);
         if constexpr (HAS_CSG && !REDO) {
             if (deferred && !(shadow && found)) {                     // (an occluded shadow test needs no composite any more)
                 wk = wk_before; cam = cam_before;                     // its record is written, and its work counted, by the second run
@@ -378,7 +375,7 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
             }
         }
         const bool settled = shadow && found;                        // an occluded shadow test needs no more work
-        jobs.U(cap, JQ_FOUND, q) = !found ? 0u : shadow ? 1u : 1u | (((sc.shader_bounds[sc.instances[h.inst].shader] & 0xFFFFu) ? 2u : 1u) << 1);
+        jobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
         jobs.U(cap, JQ_FLAGS, q) = (shadow ? 1u : 0u) | (settled ? 2u : 0u);
         if (!shadow) {                                                // (of a shadow test only the verdict is kept)
             jobs.F(cap, JQ_T, q) = h.t;
@@ -467,7 +464,7 @@ k_wf_ties(DScene sc, DRenderParams rp, WfArgs a) {
         const uint32_t q = tie_entries[3 * e];
         bool first = true;
         for (uint32_t k = 0; k < e; ++k) first = first && tie_entries[3 * k] != q;
-        if (!first || !(a.rjobs.U(cap, JQ_FOUND, q) & 1u)) continue;
+        if (!first || !a.rjobs.U(cap, JQ_FOUND, q)) continue;
         const d3 o = a.rays.ld3(cap, RQ_O, q), d = a.rays.ld3(cap, RQ_D, q);
         SceneHit h;
         h.t = a.rjobs.F(cap, JQ_T, q); h.inst = a.rjobs.U(cap, JQ_INST, q);
@@ -478,7 +475,6 @@ k_wf_ties(DScene sc, DRenderParams rp, WfArgs a) {
         if (changed) {
             a.rjobs.F(cap, JQ_T, q) = h.t; a.rjobs.F(cap, JQ_CT, q) = h.c.t;
             a.rjobs.U(cap, JQ_INST, q) = h.inst; a.rjobs.U(cap, JQ_CA, q) = h.c.a; a.rjobs.U(cap, JQ_CB, q) = h.c.b;
-            a.rjobs.U(cap, JQ_FOUND, q) = 1u | (((sc.shader_bounds[sc.instances[h.inst].shader] & 0xFFFFu) ? 2u : 1u) << 1);
         }
     }
     __syncthreads();
@@ -576,14 +572,11 @@ k_wf_walk(DScene sc, WfArgs a) {
     auto finish_query = [&]() {
         if (qchanged) {                                               // (else the analytic phase's record stands)
             const WfQueue& jobs = qshadow ? a.sjobs : a.rjobs;
-            if (qshadow) jobs.U(a.cap, JQ_FOUND, qe) = 1u;            // (of a shadow test only the verdict is read)
-            else {
-                const uint32_t mi = qca >> 28;                        // the winning mesh instance's place in the table (7: or beyond it)
-                const uint32_t kind = mi < RT_WF_WALK_TABLE - 1u ? wtable[mi].kind : ((sc.shader_bounds[sc.instances[qinst].shader] & 0xFFFFu) ? 2u : 1u);
-                jobs.U(a.cap, JQ_FOUND, qe) = 1u | (kind << 1);
+            jobs.U(a.cap, JQ_FOUND, qe) = 1u;
+            if (!qshadow) {                                           // (of a shadow test only the verdict is read)
                 jobs.F(a.cap, JQ_T, qe) = qt; jobs.F(a.cap, JQ_CT, qe) = qct;
                 jobs.U(a.cap, JQ_INST, qe) = qinst;
-                jobs.U(a.cap, JQ_CA, qe) = qca & 0x0FFFFFFFu; jobs.U(a.cap, JQ_CB, qe) = 0u;
+                jobs.U(a.cap, JQ_CA, qe) = qca; jobs.U(a.cap, JQ_CB, qe) = 0u;
             }
         }
         have = false;
@@ -657,7 +650,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                     inclusive = (wi.is_root & RT_INST_ROOT) != 0;
                     RT_COUNT(wk, box_tests);
                     double tn;
-                    if (slab(wi.lo, wi.hi, lr.o, inv, tmax, tn) && !(qshadow && (wi.is_root & RT_INST_CLEAR_TO_LIGHT))) {
+                    if (slab(wi.lo, wi.hi, lr.o, inv, tmax, tn) && !(sc.has_clear_to_light && qshadow && (wi.is_root & RT_INST_CLEAR_TO_LIGHT))) {
                         walking = true; cur = 0; sp = 0; found = false; best = tmax;
                         if (LDS) { s32 = slab32_setup(lr.o, inv, wi.max_abs); best32 = slab32_limit(best); }
                         gnodes = sc.bvh_nodes + wi.node_off; gtris = sc.mesh_tris + wi.tri_off;
@@ -742,7 +735,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                         double tw = best * inv_s;
                         if (replaces_hit(tw, inst, qt, qinst, qfound != 0u)) {
                             qt = tw; qinst = inst; qfound = 1u; qchanged = true;
-                            qct = best; qca = tri | (min(m, 7u) << 28);   // (with the mesh instance's place in the table: finish_query looks its material's list up there)
+                            qct = best; qca = tri;
                         }
                     }
                 }
@@ -879,8 +872,7 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
                     RT_COUNT(wk, shade_evals);
                 }
             } else if (!(a.rjobs.U(cap, JQ_FLAGS, q) & 4u)) {
-                const uint32_t fw = a.rjobs.U(cap, JQ_FOUND, q);
-                if (!(fw & 1u)) {
+                if (!a.rjobs.U(cap, JQ_FOUND, q)) {
                     if (batch_misses) missed = true;
                     else {
                         cslot = a.rays.U(cap, RQ_SLOT, q);
@@ -888,7 +880,8 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
                         if (a.rays.U(cap, RQ_FLAGS, q) & 1u) { a.distance[cslot] = INFINITY; a.hit_id[cslot] = 0xFFFFFFFFu; }
                     }
                 } else {
-                    kind = fw >> 1;
+                    const uint32_t bounds = sc.shader_bounds[sc.instances[a.rjobs.U(cap, JQ_INST, q)].shader];
+                    kind = (bounds & 0xFFFFu) ? 2u : 1u;
                 }
             }
         }

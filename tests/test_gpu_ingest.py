@@ -349,6 +349,18 @@ def test_obj_reader_errors(render_mod):
     with pytest.raises(render_mod.RtError) as e:
         render_mod.obj_parse(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n")
     assert e.value.code == 1
+    # what the reference's parser (tobj 0.1.7) fails on or reads differently is refused, not guessed at:
+    # line / point elements, a v / vt / vn line with too few numbers, a token that is no decimal number
+    tri = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n"
+    for bad in (tri + b"l 1 2\n", tri + b"p 1\n", b"v 0 0\n" + tri, b"vt 0.5\n" + tri, b"vn 0 1\n" + tri,
+                b"v 1.0f 0 0\n" + tri, b"v 0x10 0 0\n" + tri, b"v - 0 0\n" + tri, b"v 1 2 # three\n" + tri):
+        with pytest.raises(render_mod.RtError) as e:
+            render_mod.obj_parse(bad)
+        assert e.value.code == 2, bad
+    # a material line after faces opens no new model when no material library was read (none ever is: the
+    # text is all the reader gets), so the corners before and after it share their vertices
+    got = render_mod.obj_parse(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\nusemtl b\nf 3 2 1\n")
+    assert got["positions"].shape == (3, 3) and got["faces"].tolist() == [[0, 1, 2], [2, 1, 0]]
 
 
 def test_unknown_ingest_mode_is_refused(render_mod, scene_cache):
