@@ -499,7 +499,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     const uint32_t walk_cus_max = fixed_mem ? std::min(128u, (uint32_t)s->num_cus) : (uint32_t)s->num_cus;
     const size_t walk_overflow_bytes = (size_t)(fixed_mem ? 1u : 4u) * walk_cus_max * 2048u * (RT_BVH_STACK - RT_WF_LDS_STACK) * 4u;   // per chain: a walk launch with up to 2048 threads per CU
     // (the static scratch array also holds the tie lists: RT_WF_Q * RT_WF_TIE_WORDS words, within the slack below)
-    const size_t wf_entry_bytes = 2 * (RQ_NF * 8 + RQ_NU * 4) + 2 * (SQ_NF * 8 + SQ_NU * 4) + 2 * (JQ_NF * 8 + JQ_NU * 4) +
+    const size_t wf_entry_bytes = 2 * RT_WF_RAY_BYTES + 2 * RT_WF_SHADOW_BYTES + 2 * (JQ_NF * 8 + JQ_NU * 4) +
                                   2 * sizeof(uint32_t) +
                                   ((s->ds.features & RTF_CSG) ? 2 * sizeof(uint32_t) : 0);
     // queue pipeline: s->wf_scale entries per pixel (and queue) of this rank's share, every queue cut into RT_WF_Q sub-queues
@@ -595,8 +595,8 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     uint32_t gen0_tiles = 0;               // generation 0 dealt out in tiles: bit 0 pass 1, bit 1 AA resolve
     if (wavefront) {
         const size_t n = (size_t)(wf_cap / RT_WF_Q) * RT_WF_Q;    // entries per array; doubles first, then the words
-        for (auto& b : w.wf_rays) if ((e = b.ensure(n * (RQ_NF * 8 + RQ_NU * 4))) != RT_OK) return e;
-        for (auto& b : w.wf_shadows) if ((e = b.ensure(n * (SQ_NF * 8 + SQ_NU * 4))) != RT_OK) return e;
+        for (auto& b : w.wf_rays) if ((e = b.ensure(n * RT_WF_RAY_BYTES)) != RT_OK) return e;
+        for (auto& b : w.wf_shadows) if ((e = b.ensure(n * RT_WF_SHADOW_BYTES)) != RT_OK) return e;
         if ((e = w.wf_rjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_sjobs.ensure(n * (JQ_NF * 8 + JQ_NU * 4))) != RT_OK) return e;
         if ((e = w.wf_walk_list.ensure(2 * n * sizeof(uint32_t))) != RT_OK) return e;
@@ -636,9 +636,10 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
         wa.gen0_tiles = (gen0_tiles >> mode) & 1u;
         wa.list = (const uint32_t*)w.list.p;
         // generation 0 into queue set 0
-        auto queue = [](const DeviceBuf& b, size_t entries, size_t nf) { WfQueue q; q.f = (double*)b.p; q.u = (uint32_t*)((char*)b.p + entries * nf * 8); return q; };
+        auto ray_queue = [](const DeviceBuf& b) { RayQueue q; q.f = (double*)b.p; q.u = nullptr; return q; };
+        auto shadow_queue = [](const DeviceBuf& b) { ShadowQueue q; q.f = (double*)b.p; q.u = nullptr; return q; };
         const size_t n = wa.cap;
-        wa.out_rays = queue(w.wf_rays[0], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[0], n, SQ_NF); wa.n_out = ws + WF_N;
+        wa.out_rays = ray_queue(w.wf_rays[0]); wa.out_shadows = shadow_queue(w.wf_shadows[0]); wa.n_out = ws + WF_N;
         hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, stream, rp, wa);
         HIP_TRY(hipGetLastError());
         uint32_t chains = fixed_mem ? 1u : wf_chains((size_t)W * num_rows);
@@ -651,8 +652,8 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
             for (uint32_t c = 1; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(s->chain_stream[c - 1], s->chain_fork, 0));
         }
         for (uint32_t g = 0; g < generations; ++g) {
-            wa.rays = queue(w.wf_rays[g & 1], n, RQ_NF); wa.shadows = queue(w.wf_shadows[g & 1], n, SQ_NF); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
-            wa.out_rays = queue(w.wf_rays[(g + 1) & 1], n, RQ_NF); wa.out_shadows = queue(w.wf_shadows[(g + 1) & 1], n, SQ_NF); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
+            wa.rays = ray_queue(w.wf_rays[g & 1]); wa.shadows = shadow_queue(w.wf_shadows[g & 1]); wa.n_in = ws + WF_N + 2 * RT_WF_Q * g;
+            wa.out_rays = ray_queue(w.wf_rays[(g + 1) & 1]); wa.out_shadows = shadow_queue(w.wf_shadows[(g + 1) & 1]); wa.n_out = ws + WF_N + 2 * RT_WF_Q * (g + 1);
             wa.walk_count = ws + WF_WALK_COUNT + RT_WF_Q * g;
             wa.csg_count = (unsigned int*)w.wf_scalars.p + WF_CSG_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
             wa.hit_count = (unsigned int*)w.wf_scalars.p + WF_HIT_COUNT + (mode * (WF_MAX_GEN + 1) + g) * 2 * RT_WF_Q;
@@ -939,6 +940,15 @@ int rt_render(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam, 
             double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B] + c.prof[PF_CYC_FETCH]) + 1e-30;
             std::fprintf(stderr, "[rt] wave time: A %.1f%% T %.1f%% B %.1f%% fetch/hand-on %.1f%%\n", 100.0 * c.prof[PF_CYC_A] / tot, 100.0 * c.prof[PF_CYC_T] / tot,
                          100.0 * c.prof[PF_CYC_B] / tot, 100.0 * c.prof[PF_CYC_FETCH] / tot);
+        }
+        if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work && s->last_used_queues && std::getenv("RT_WF_DEBUG") && (std::atoi(std::getenv("RT_WF_DEBUG")) & 16)) {
+            DCounters c{};
+            HIP_TRY(hipMemcpy(&c, static_cast<char*>(s->ws.scalars.p) + SCALAR_BYTES, sizeof c, hipMemcpyDeviceToHost));
+            const double tot = (double)(c.prof[PF_CYC_A] + c.prof[PF_CYC_T] + c.prof[PF_CYC_B]) + 1e-30;
+            std::fprintf(stderr, "[rt] walk kernel, wave cycles: refill %.1f%% (%.0f per trip), descent %.1f%% (%.0f per step), leaves %.1f%% (%.0f per trip)\n",
+                         100.0 * c.prof[PF_CYC_A] / tot, (double)c.prof[PF_CYC_A] / ((double)c.prof[PF_T_REFILLS] + 1e-30),
+                         100.0 * c.prof[PF_CYC_T] / tot, (double)c.prof[PF_CYC_T] / ((double)c.prof[PF_T_ITERS] + 1e-30),
+                         100.0 * c.prof[PF_CYC_B] / tot, (double)c.prof[PF_CYC_B] / ((double)c.prof[PF_T_LEAF_ITERS] + 1e-30));
         }
         if (std::getenv("RT_DEBUG_ROUNDS") && aux && aux->count_work && s->last_used_queues) {   // where the shade kernel's waves spend their time
             DCounters c{};

@@ -55,28 +55,54 @@ RT_DEV WalkInst walk_inst(const DScene& sc, uint32_t m) {
 // holds an even sample of the frame (every 256th pixel) and stays about as long as the others.
 #define RT_WF_Q 256u
 
-// Queue entries are stored field by field (structure of arrays): entry e of a queue with `cap`
-// entries keeps field k at f[k*cap + e] (doubles) / u[k*cap + e] (words), so that the 64 lanes of
-// a wave, which work on consecutive entries, read and write whole cache lines per instruction.
-struct WfQueue {
-    double* f;
-    uint32_t* u;
-    RT_DEV double& F(uint32_t cap, uint32_t k, uint32_t e) const { return f[(size_t)k * cap + e]; }
-    RT_DEV uint32_t& U(uint32_t cap, uint32_t k, uint32_t e) const { return u[(size_t)k * cap + e]; }
+// Queue entries.  The records of traced queries (TraceJob) are stored field by field (structure of arrays): entry e
+// of a queue with `cap` entries keeps field k at f[k*cap + e] (doubles) / u[k*cap + e] (words); the kernels that
+// read them densely take a field or two each.  Rays and shadow tests are stored as records, cut into the two
+// parts their readers take together:
+//   ray         part A, 64 bytes: origin, direction, depth, path, slot, flags   (analytic kernel, walk, shading)
+//               part B, 48 bytes: weight, contribution                          (shading; misses)
+//   shadow test part A, 64 bytes: origin, direction, distance, slot (RT_NO_SLOT marks a hole)   (analytic kernel, walk)
+//               part B, 32 bytes: weight, slot                                  (k_wf_settle, for the tests nothing blocks)
+// with all parts A of a queue first, then all parts B.  A lane reads or writes a whole part with 16-byte
+// instructions; the shade kernels, which take their hits from lists (every third or fourth entry of a
+// sub-queue), then fetch whole 64-byte sectors they use fully instead of a sector per field, and what a lane
+// appends fills its sectors at once instead of leaving them half written until the next field's store.
+enum { QK_JOB = 0, QK_RAY = 1, QK_SHADOW = 2 };
+template <int KIND>
+struct WfQueueT {
+    double* f;                        // QK_JOB: the doubles' arrays; records: the buffer
+    uint32_t* u;                      // QK_JOB: the words' arrays
+    static constexpr uint32_t A_BYTES = 64u, B_BYTES = KIND == QK_RAY ? 48u : 32u, A_DOUBLES = KIND == QK_RAY ? 6u : 7u;
+    RT_DEV uint8_t* part_a(uint32_t e) const { return reinterpret_cast<uint8_t*>(f) + (size_t)e * A_BYTES; }
+    RT_DEV uint8_t* part_b(uint32_t cap, uint32_t e) const { return reinterpret_cast<uint8_t*>(f) + (size_t)cap * A_BYTES + (size_t)e * B_BYTES; }
+    RT_DEV double& F(uint32_t cap, uint32_t k, uint32_t e) const {
+        if constexpr (KIND == QK_JOB) return f[(size_t)k * cap + e];
+        else return k < A_DOUBLES ? reinterpret_cast<double*>(part_a(e))[k] : reinterpret_cast<double*>(part_b(cap, e))[k - A_DOUBLES];
+    }
+    RT_DEV uint32_t& U(uint32_t cap, uint32_t k, uint32_t e) const {
+        if constexpr (KIND == QK_JOB) return u[(size_t)k * cap + e];
+        else if constexpr (KIND == QK_RAY) return reinterpret_cast<uint32_t*>(part_a(e) + 48u)[k];
+        else return k == 0u ? reinterpret_cast<uint32_t*>(part_a(e) + 56u)[0] : reinterpret_cast<uint32_t*>(part_b(cap, e) + 24u)[0];
+    }
     RT_DEV d3 ld3(uint32_t cap, uint32_t k, uint32_t e) const { return mk3(F(cap, k, e), F(cap, k + 1, e), F(cap, k + 2, e)); }
     RT_DEV void st3(uint32_t cap, uint32_t k, uint32_t e, d3 v) const { F(cap, k, e) = v.x; F(cap, k + 1, e) = v.y; F(cap, k + 2, e) = v.z; }
 };
+typedef WfQueueT<QK_JOB> WfQueue;     // (the records of traced queries)
+typedef WfQueueT<QK_RAY> RayQueue;
+typedef WfQueueT<QK_SHADOW> ShadowQueue;
+#define RT_WF_RAY_BYTES 112u          // per entry of a ray queue (parts A + B)
+#define RT_WF_SHADOW_BYTES 96u        // per entry of a shadow-test queue
 // rays (the fields of LaneRay): 12 doubles, 4 words
 enum { RQ_O = 0, RQ_D = 3, RQ_W = 6, RQ_C = 9, RQ_NF = 12, RQ_DEPTH = 0, RQ_PATH = 1, RQ_SLOT = 2, RQ_FLAGS = 3, RQ_NU = 4 };
-// shadow tests (ShadowJob): 10 doubles, 1 word
-enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_NU = 1 };
+// shadow tests (ShadowJob): 10 doubles, the slot twice (SQ_SLOT in part A, SQ_SLOT_B in part B)
+enum { SQ_O = 0, SQ_D = 3, SQ_DIST = 6, SQ_W = 7, SQ_NF = 10, SQ_SLOT = 0, SQ_SLOT_B = 1, SQ_NU = 2 };
 // query records (TraceJob): 2 doubles, 5 words
 enum { JQ_T = 0, JQ_CT = 1, JQ_NF = 2, JQ_INST = 0, JQ_FOUND = 1, JQ_CA = 2, JQ_CB = 3, JQ_FLAGS = 4, JQ_NU = 5 };
 
 struct WfArgs {
     // queries of the current generation; sub-queue s holds rays [s*sub, s*sub + n_in[2s]) and
     // shadow tests [s*sub, s*sub + n_in[2s+1]) of their arrays
-    WfQueue rays, shadows, rjobs, sjobs;
+    RayQueue rays; ShadowQueue shadows; WfQueue rjobs, sjobs;
     const unsigned int* n_in;
     uint32_t sub;                     // capacity of one sub-queue
     uint32_t cap;                     // RT_WF_Q * sub: entries per array
@@ -85,7 +111,7 @@ struct WfArgs {
     // sub-queues of its own: this launch works on sub-queues [sq_base, sq_base + sq_count).
     uint32_t sq_base, sq_count;
     // the next generation
-    WfQueue out_rays, out_shadows;
+    RayQueue out_rays; ShadowQueue out_shadows;
     unsigned int* n_out;
     // mesh walk
     uint32_t* walk_list;              // RT_WF_Q lists of 2*sub query ids: ray i -> i, shadow test i -> i | 0x80000000
@@ -119,14 +145,14 @@ struct WfArgs {
     uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
     uint32_t* tie_list;               // per sub-queue RT_WF_TIE_WORDS words (k_wf_analytic -> k_wf_ties), all counts zero between launches
     uint32_t shade_lists;             // k_wf_shade: the hit lists this launch works on (bit 0: materials without rays, bit 1: the others)
-    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests
+    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests, 8 the shade kernels' own colour terms; 16: the walk kernel's cycles per section instead of the shade kernels'
 };
 
 RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags);   // (below, with the shading phase)
 
 // The shader tree's rays go straight into the next generation's queues, at positions reserved beforehand.
 struct QueueSink {
-    WfQueue rays, shadows;
+    RayQueue rays; ShadowQueue shadows;
     uint32_t cap;
     // Reserved entries: one run per lane and queue.  (Laying a wave's reservation out in planes —
     // first new ray of every lane, then the second, ... — makes the stores denser but was measured
@@ -156,7 +182,7 @@ struct QueueSink {
         const uint32_t e = shadow_entry(nshadows++);
         if (dry) return;
         shadows.st3(cap, SQ_O, e, o); shadows.st3(cap, SQ_D, e, d); shadows.F(cap, SQ_DIST, e) = dist;
-        shadows.st3(cap, SQ_W, e, parent_w * w); shadows.U(cap, SQ_SLOT, e) = slot;
+        shadows.st3(cap, SQ_W, e, parent_w * w); shadows.U(cap, SQ_SLOT, e) = slot; shadows.U(cap, SQ_SLOT_B, e) = slot;
     }
     template <class K>
     RT_DEV void scale(uint32_t from, uint32_t to, K k) {
@@ -224,7 +250,7 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
             dir = camera_dir(rp.cam, (double)x + 0.5 + ax * rand_distance, (double)y + 0.5 + ay * rand_distance);
             slot = item;
         }
-        const WfQueue& r = a.out_rays;
+        const RayQueue& r = a.out_rays;
         r.st3(a.cap, RQ_O, e, cam_o); r.st3(a.cap, RQ_D, e, dir);
         r.st3(a.cap, RQ_W, e, mk3(1.0, 1.0, 1.0)); r.st3(a.cap, RQ_C, e, mk3(1.0, 1.0, 1.0));
         r.U(a.cap, RQ_DEPTH, e) = rp.recursion_depth; r.U(a.cap, RQ_PATH, e) = 1u;
@@ -581,6 +607,9 @@ k_wf_walk(DScene sc, WfArgs a) {
         }
         have = false;
     };
+    const bool sections = COUNT && (a.debug & 16u) != 0;             // (timing experiments: where a wave's cycles go)
+    long long t_sec = sections ? clock64() : 0;
+    unsigned long long cyc_refill = 0, cyc_descend = 0, cyc_leaf = 0;
     for (;;) {
         const bool need = !walking && (have || !dry);
         const unsigned long long nmask = __ballot(need), wmask = __ballot(walking);
@@ -662,6 +691,7 @@ k_wf_walk(DScene sc, WfArgs a) {
                 } while (!walking && have);
             }
         }
+        if (sections) { const long long t1 = clock64(); cyc_refill += (unsigned long long)(t1 - t_sec); t_sec = t1; }
         const uint32_t nwalk = (uint32_t)__popcll(__ballot(walking));
         while (walking && !(cur & 0x80000000u)) {                   // descend to a leaf
             // (lanes still here: those descending) most of the wave waits at its leaves -> test those first
@@ -707,6 +737,7 @@ k_wf_walk(DScene sc, WfArgs a) {
             else if (h1) cur = c1;
             else cur = pop();
         }
+        if (sections) { const long long t1 = clock64(); cyc_descend += (unsigned long long)(t1 - t_sec); t_sec = t1; }
         if (walking) {
             if (cur != RT_WALK_DONE && (cur & 0x80000000u)) {         // the leaf's triangles
                 RT_PROF(wk, PF_T_LEAF_ITERS, PF_T_LEAF_LANES);
@@ -744,8 +775,12 @@ k_wf_walk(DScene sc, WfArgs a) {
                 walking = false;
             }
         }
+        if (sections) { const long long t1 = clock64(); cyc_leaf += (unsigned long long)(t1 - t_sec); t_sec = t1; }
     }
-    if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
+    if (COUNT) {
+        if (sections && (threadIdx.x & 63u) == 0u) { wk.prof[PF_CYC_A] = cyc_refill; wk.prof[PF_CYC_T] = cyc_descend; wk.prof[PF_CYC_B] = cyc_leaf; }
+        flush_counters<COUNT>(a.counters, wk, 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------ shading phase
@@ -867,7 +902,7 @@ k_wf_settle(DScene sc, DRenderParams rp, WfArgs a) {
         if (ql < nq) {
             if (ql >= nr) {                                           // shadow test: the light's term counts if nothing blocks it
                 if (!(a.sjobs.U(cap, JQ_FLAGS, q) & 4u) && !a.sjobs.U(cap, JQ_FOUND, q)) {
-                    cslot = a.shadows.U(cap, SQ_SLOT, q);
+                    cslot = a.shadows.U(cap, SQ_SLOT_B, q);
                     cval = a.shadows.ld3(cap, SQ_W, q);
                     RT_COUNT(wk, shade_evals);
                 }
@@ -1004,9 +1039,10 @@ k_wf_shade(DScene gsc, DRenderParams rp, WfArgs a) {
             for (uint32_t i = sink.nrays; i < want_rays; ++i) a.out_rays.U(cap, RQ_FLAGS, sink.ray_entry(i)) = 8u;          // holes
             for (uint32_t i = sink.nshadows; i < want_shadows; ++i) a.out_shadows.U(cap, SQ_SLOT, sink.shadow_entry(i)) = RT_NO_SLOT;
         }
-        RT_PROF_CYC(wk, PF_CYC_A, t_prof);                                // holes
+        if (!(a.debug & 16u)) RT_PROF_CYC(wk, PF_CYC_A, t_prof);          // holes
+        if (a.debug & 8u) cslot = RT_NO_SLOT;
         wave_accumulate(stage, cslot, cval, a.acc, a.acc_flags);
-        RT_PROF_CYC(wk, PF_CYC_T, t_prof);                                // accumulation
+        if (!(a.debug & 16u)) RT_PROF_CYC(wk, PF_CYC_T, t_prof);          // accumulation
     }
     if (COUNT) flush_counters<COUNT>(a.counters, wk, 0, 0);
 }
