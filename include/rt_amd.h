@@ -309,9 +309,15 @@ int rt_frame_status(const RtScene* scene, uint64_t* dropped);
  * about 13 entries per pixel; rt_render_device starts with 8 and at least 2^20) and cannot grow:
  * pair the call with rt_frame_status, which returns RT_ERR_CAPACITY for a frame that outgrew them.
  * Larger frames: rt_render_device.
- * All calls on one GPU — on whichever scene — share that GPU's array: calls that overlap on one
- * GPU (two streams, two host threads with different scenes) race.  Calls issued one after the other
- * on one stream are safe. */
+ * The call consists of stream operations only (launches, memsets, one copy into pinned memory; no
+ * event, no synchronisation): once an ordinary call has run on the device (kernels loaded, LDS
+ * limits granted) it may be captured into a HIP graph and replayed.
+ * All calls on one GPU — on whichever scene or stream — share that GPU's array.  Outside capture
+ * they take turns on it (each waits for the previous one's last kernel through a per-device event);
+ * graphs that contain the call, and a graph against a direct call, are NOT kept apart: their owner
+ * must order them, or they race on the array.
+ * Cost: the array is part of the library's code object, so every process that loads the library
+ * holds RT_NOALLOC_SCRATCH_BYTES of device memory on each GPU it touches, used or not. */
 #define RT_NOALLOC_SCRATCH_BYTES (256u << 20)
 #define RT_NOALLOC_MAX_PIXELS 32768u
 int rt_render_device_noalloc(const RtScene* scene, const RtImageDim* dim, const RtCamera* cam,
@@ -343,7 +349,21 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
  * triangle fans; positions, normals and texture coordinates parsed as f32 and widened), parsed on
  * `device`.  The arrays are host memory owned by the library until rt_obj_release; they are what
  * RtMesh / mesh_f64 / mesh_u32 of an RtSceneDesc take.  Texture coordinates and normals exist only
- * for vertices whose corner names one, like the reference's arrays. */
+ * for vertices whose corner names one, like the reference's arrays.
+ * tobj's source is not part of the reference tree (a Cargo dependency), so the match is pinned on the
+ * reference's own .obj assets and on a sequential reader of the same rules, not on tobj itself.
+ * Where tobj is known to read a text differently, the text is refused rather than guessed at:
+ *   - `l` and `p` elements (tobj sends them through its face path, where they add vertices):
+ *     RT_ERR_UNSUPPORTED;
+ *   - a v / vn line with fewer than three numbers, a vt line with fewer than two, a token that is
+ *     no decimal number ("1.0f", hex floats; tobj fails the whole load): RT_ERR_UNSUPPORTED;
+ *   - a face that names a vertex, texture coordinate or normal the text does not hold:
+ *     RT_ERR_INVALID_ARG.
+ * Materials are ignored: only the text is read, never a .mtl file, and without a resolved material
+ * library tobj opens no new model at a `usemtl` line either, so models are bounded by o / g lines
+ * alone.  Whether a model has texture coordinates / normals is decided from the counts of the whole
+ * text, not from the counts at the point where tobj would export the model; the two differ only for
+ * texts that define their first vt / vn after a model that uses none. */
 typedef struct RtObjMesh {
     uint32_t num_positions, num_normals, num_texcoords, num_faces;
     double* positions;     /* 3 per vertex */

@@ -554,8 +554,13 @@ k_wf_walk(DScene sc, WfArgs a) {
     }
     const uint32_t nm = sc.num_mesh_instances;
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t* gstack = a.walk_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (RT_BVH_STACK - RT_WF_LDS_STACK);
+    // (the thread's overflow stack in global memory; its address is worked out where it is needed, which is rare, instead of
+    // being kept in two registers the kernel does not have)
+    auto gstack = [&]() -> uint32_t* {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return a.walk_overflow + (size_t)(blockIdx.x * blockDim.x + t) * (RT_BVH_STACK - RT_WF_LDS_STACK);
+    };
     Work<COUNT> wk = {};
     // The chain's walk lists are read as one: `starts` holds where each begins in the joint numbering.
     uint32_t chunk_next = 0, chunk_end = 0, chunk_list = 0;          // the wave's reserved part of the joint list, and the list its first entry lies in
@@ -581,7 +586,7 @@ k_wf_walk(DScene sc, WfArgs a) {
     int sp = 0;
     auto push = [&](uint32_t v) {
         if (sp < RT_WF_LDS_STACK) lstack[sp * lstride] = v;
-        else if (sp < RT_BVH_STACK) gstack[sp - RT_WF_LDS_STACK] = v;
+        else if (sp < RT_BVH_STACK) gstack()[sp - RT_WF_LDS_STACK] = v;
         ++sp;
     };
     // (the LDS part of the stack through a pointer that says so: otherwise the compiler merges the
@@ -592,7 +597,7 @@ k_wf_walk(DScene sc, WfArgs a) {
         if (sp == 0) return RT_WALK_DONE;
         --sp;
         if (sp < RT_WF_LDS_STACK) return lstack3[sp * lstride];
-        return gstack[sp - RT_WF_LDS_STACK];
+        return gstack()[sp - RT_WF_LDS_STACK];
     };
     bool qchanged = false;                                           // a mesh took the query's answer over
     auto finish_query = [&]() {
@@ -619,7 +624,8 @@ k_wf_walk(DScene sc, WfArgs a) {
             const bool want = need && !have;
             const unsigned long long jm = __ballot(want);
             if (jm) {
-                const uint32_t nwant = (uint32_t)__popcll(jm), rank = (uint32_t)__popcll(jm & lt);
+                const uint32_t nwant = (uint32_t)__popcll(jm);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(jm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)jm, 0u));   // wanting lanes below this one
                 // (wave-uniform) a used-up chunk -> reserve the next portion of the joint list
                 if (chunk_next >= chunk_end || chunk_next >= total) {
                     uint32_t base = 0;
