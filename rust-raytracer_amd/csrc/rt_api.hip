@@ -139,6 +139,7 @@ struct RtScene {
     // Shade kernel of the queue pipeline per hit list (materials without / with rays): 0 the general kernel, 1 / 2 the
     // kernel built for a class of simple materials (k_wf_shade in rt_wavefront.h), when every material on the list is of it
     int shade_cls[2] = {0, 0};
+    bool shade_none[2] = {false, false};   // no material of the scene belongs on that hit list: its launch is left out
     bool ties_possible = false;            // two or more instances of the kinds whose ties k_wf_ties decides
     uint32_t wf_scale = 8;                 // queue entries per pixel of the frame; doubled when a generation did not fit
     bool last_used_queues = false, queue_overflowed = false;
@@ -281,6 +282,7 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
         const uint32_t glass = (1u << DS_REFLECTION) | (1u << DS_TRANSLUCENT) | (1u << DS_COMPOSITE);
         if (allow && fs.shade_kinds[0] == (1u << DS_PHONG) && fs.shade_depth[0] == 0) s->shade_cls[0] = 1;
         if (allow && fs.shade_kinds[1] != 0 && (fs.shade_kinds[1] & ~glass) == 0 && fs.shade_depth[1] <= 1) s->shade_cls[1] = 2;
+        s->shade_none[0] = fs.shade_kinds[0] == 0; s->shade_none[1] = fs.shade_kinds[1] == 0;
     }
     {   // LDS-resident BVH when every mesh fits beside nothing else in one CU's LDS
         while (fs.lds_blob.size() % 16) fs.lds_blob.push_back(0);
@@ -691,11 +693,13 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
                     lrc = wf_launch(1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                     if (lrc != RT_OK) return lrc;
                 } else {                                                 // a launch per list, each on the kernel for its materials
+                    // (a list no material of the scene belongs on stays empty: even so its launch would cost tens of
+                    // microseconds per generation, the general kernel's 960 bytes of scratch per lane to be set up)
                     wa.shade_lists = 2u;
-                    lrc = wf_launch(s->shade_cls[1] ? 3 + s->shade_cls[1] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    lrc = s->shade_none[1] ? RT_OK : wf_launch(s->shade_cls[1] ? 3 + s->shade_cls[1] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                     if (lrc != RT_OK) return lrc;
                     wa.shade_lists = 1u;
-                    lrc = wf_launch(s->shade_cls[0] ? 3 + s->shade_cls[0] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
+                    lrc = s->shade_none[0] ? RT_OK : wf_launch(s->shade_cls[0] ? 3 + s->shade_cls[0] : 1, s->ds.features, count_work, cgrid, cs, s->ds, rp, wa);
                     if (lrc != RT_OK) return lrc;
                 }
             }

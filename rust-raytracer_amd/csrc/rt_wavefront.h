@@ -318,8 +318,12 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 // nor its scratch memory.
 // LDS: [small scene tables][sky-box scenes: per wave 64 x 10 words of staging, per wave 128 list entries]
 #define RT_WF_TIE_WORDS (4u + RT_TIE_LIST * 3u)   // a sub-queue's list of noted tie decisions: count, then (query, instance, instance) triples
+// (The second run fits three waves per SIMD without spilling - 167 registers against 171 when left alone - and
+// gains from the third: subtraction_outside 4K 57.9 -> 52.3 ms together with the empty shade launches left out.  The
+// first run held to three waves spills 22 registers and loses: 53.9 ms.)
+#define RT_REDO_WAVES 3
 template <uint32_t F, bool COUNT, bool HOT, bool REDO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REDO ? RT_REDO_WAVES : 1)))
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     constexpr bool HAS_CSG = (F & RTF_CSG) != 0;
