@@ -145,7 +145,7 @@ struct WfArgs {
     uint32_t gen0_tiles;              // generation 0 dealt out in runs of 64 neighbouring rays (8 x 8 pixel tiles) instead of ray by ray
     uint32_t* tie_list;               // per sub-queue RT_WF_TIE_WORDS words (k_wf_analytic -> k_wf_ties), all counts zero between launches
     uint32_t shade_lists;             // k_wf_shade: the hit lists this launch works on (bit 0: materials without rays, bit 1: the others)
-    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests, 8 the shade kernels' own colour terms; 16: the walk kernel's cycles per section instead of the shade kernels'; 32 / 64: the walk kernel leaves before / after copying the hierarchy into LDS
+    uint32_t debug;                   // timing experiments only (RT_WF_DEBUG): 1 skips hit reconstruction and shading, 2 shading, 4 the stores of new rays and shadow tests, 8 the shade kernels' own colour terms; 16: the walk kernel's cycles per section instead of the shade kernels'
 };
 
 RT_DEV void wave_accumulate(unsigned long long* stage, uint32_t slot, d3 c, unsigned long long* acc, uint32_t* acc_flags);   // (below, with the shading phase)
@@ -550,14 +550,12 @@ k_wf_walk(DScene sc, WfArgs a) {
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t chunk = min(128u, max(64u, (total / waves + 63u) & ~63u));
     if (blockIdx.x * 4u * chunk >= total) return;                    // one portion per SIMD of a staying workgroup (also: nothing to walk at all)
-    if (a.debug & 32u) return;                                       // (timing experiments: the launch's cost up to here ...
     if constexpr (LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.lds_blob);
         uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(blob));
         for (uint32_t i = threadIdx.x; i < sc.lds_blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    if (a.debug & 64u) return;                                       // ... and with the hierarchy's copy)
     const uint32_t nm = sc.num_mesh_instances;
     const uint32_t lane = threadIdx.x & 63u;
     // (the thread's overflow stack in global memory; its address is worked out where it is needed, which is rare, instead of
