@@ -563,6 +563,7 @@ int enqueue_frame(RtScene* s, Workspace& w, const RtImageDim& dim, const RtCamer
     ta.distance = (double*)w.distance.p; ta.hit_id = (uint32_t*)w.hit_id.p;
     ta.list = nullptr; ta.count = aa_count; ta.counters = counters; ta.mode = 0;
     ta.refill_min = refill_min();
+    { const char* te = std::getenv("RT_WF_TIES"); ta.exact_ties = (s->ties_possible && !(te && std::atoi(te) == 0)) ? 1u : 0u; }   // (read per frame, like the queue pipeline's)
     ta.batch = batch; ta.wide_sp_limit = wide_sp_limit; ta.lane_mem = (uint8_t*)w.lane_mem.p;
     ta.queue_cap = queue_cap; ta.acc = (unsigned long long*)w.acc.p; ta.acc_flags = (uint32_t*)w.acc_flags.p;
     // Rounds: a launch ends once its work has all been dealt out, and what the lanes still hold is

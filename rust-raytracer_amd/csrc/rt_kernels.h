@@ -147,6 +147,7 @@ struct TraceArgs {
     uint32_t queue_cap;
     unsigned long long* acc;  // one accumulator (RT_ACC_LIMBS words) per sample slot, all zero between frames
     uint32_t* acc_flags;
+    uint32_t exact_ties;      // noted closest-hit ties are decided again the reference's way (scenes in which two surfaces can meet at one distance)
 };
 
 // HOT: the scene's small tables (instances, primitives, shaders, lights ...) are copied into the
@@ -334,7 +335,15 @@ k_trace(DScene gsc, DRenderParams rp, TraceArgs a) {
             }
             SceneHit h;
             h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
-            bool found = trace_scene<F, COUNT, BATCHED>(sc, o, d, shadow, max_distance, h, wk);
+            // (closest-hit decisions between two surfaces at all but one distance are noted and decided again the
+            // reference's way, level by level: exact_tie_order in rt_trace.h)
+            LaneTieLog tl;
+            tl.count = shadow ? 0u : 1u; tl.i0 = 0; tl.j0 = 0; tl.i1 = 0; tl.j1 = 0;
+            bool found = trace_scene<F, COUNT, BATCHED, true, LaneTieLog>(sc, o, d, shadow, max_distance, h, wk, nullptr, &tl);
+            if (tl.count > 1u && found && a.exact_ties) {
+                (void)resolve_tie<RT_TIE_FEATURES(F)>(sc, o, d, tl.i0, tl.j0, h);
+                if (tl.count > 2u) (void)resolve_tie<RT_TIE_FEATURES(F)>(sc, o, d, tl.i1, tl.j1, h);
+            }
             q.t = shadow ? max_distance : h.t;
             q.inst = h.inst; q.found = found ? 1u : 0u;
             q.ct = h.c.t; q.ca = h.c.a; q.cb = h.c.b;

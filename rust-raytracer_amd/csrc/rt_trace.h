@@ -1199,6 +1199,20 @@ RT_DEV bool resolve_tie(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j, Sc
     return true;
 }
 
+// A lane's own notes, for a kernel whose lanes decide their ties themselves right after the query (the persistent
+// kernel): the first two decisions of the query, in registers.  (The second look is inlined there as well: as a
+// called function it made frames of mesh scenes under area lights differ from run to run.)
+struct LaneTieLog {
+    uint32_t count;            // 0: nothing is noted (shadow tests); else 1 + the notes made
+    uint32_t i0, j0, i1, j1;
+    RT_DEV void note(uint32_t i, uint32_t j) {
+        if (count == 1u) { i0 = i; j0 = j; }
+        else if (count == 2u) { i1 = i; j1 = j; }
+        ++count;
+    }
+};
+#define RT_TIE_FEATURES(F) ((F) & (RTF_FACED | RTF_MISC | RTF_WRAP))   // what resolve_tie needs of a kernel's features: chain_distance follows no mesh and no composite
+
 // Rebuild the world-space Intersect of the winning hit (geometry/intersect.rs:31-45 applied
 // through every level at once).
 struct WorldHit {

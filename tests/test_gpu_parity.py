@@ -15,16 +15,16 @@ LSB_FRACTION = 0.999     # >= 99.9 % of pixels within 1 LSB per channel
 PSNR_DB = 50.0
 
 # Two surfaces of different nodes at one distance (coplanar touching faces, oversized walls seen along their seam):
-# the queue pipeline notes such decisions and takes them again the reference's way, through the per-level chain of
-# transforms (k_wf_ties), so those pixels agree with the oracle: scene_light_1_05 (130 seam pixels in the previous
-# build), refraction_03 (12) and the nested cubes of child_transform_test_1 need no allowance any more.
+# both schedules note such decisions and take them again the reference's way, through the per-level chain of
+# transforms (k_wf_ties in the queue pipeline, right after the query in the persistent kernel), so those pixels agree
+# with the oracle: scene_light_1_05 (130 seam pixels in an earlier build), refraction_03 (12), the nested cubes of
+# child_transform_test_1 and subdivision_light need no allowance any more.
 # What is left are decisions *inside* one primitive on rays that graze it exactly - the reference's +1.0 pixel
 # offset puts row H/2-1 and column W/2-1 on the optical axis, so a camera aimed at a symmetric solid shoots a
 # row of rays along its edges - where the last ulp of the ray in the primitive's space decides hit or miss, and
 # the composed transform of the flat instance loop is not the reference's chain of per-level ones:
 TIE_SCENES = {"octahedron_basic": 4, "octahedron_basic_02": 5,   # rays along the octahedron's edges (polyhedron.rs:99-107: inside all other planes?)
-              "triangle_basic": 2,                               # ... along the triangle's edge (plane.rs:141-164)
-              "subdivision_light": 2}                            # square light: runs on the persistent kernel, which keeps the 8-ulp rule
+              "triangle_basic": 2}                               # ... along the triangle's edge (plane.rs:141-164)
 # Scenes whose colour is ill-conditioned on a few pixels, so that the last-place differences between the flattened and the
 # per-level transforms show: (fraction of pixels within 1 LSB, PSNR)
 #   plane_texture     an infinite textured plane seen at grazing angles: thousands of units away the texel is decided by
@@ -234,9 +234,7 @@ def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatc
     ds = device_scene(name)
     dim, cam, cfg = small_view(s, width, anti_alias=True, seed=1)
     monkeypatch.delenv("RT_PATH", raising=False)
-    monkeypatch.setenv("RT_WF_TIES", "0")   # (only the queue pipeline decides exact ties the reference's way; the persistent kernel keeps the 8-ulp rule)
-    a = ds.render(dim, cam, cfg, count_work=True)
-    monkeypatch.delenv("RT_WF_TIES", raising=False)
+    a = ds.render(dim, cam, cfg, count_work=True)   # (both schedules decide exact ties the reference's way: refraction_03 holds some)
     monkeypatch.setenv("RT_PATH", "persistent")
     b = ds.render(dim, cam, cfg, count_work=True)
     monkeypatch.delenv("RT_PATH", raising=False)
