@@ -321,9 +321,9 @@ k_wf_generate(DRenderParams rp, WfArgs a) {
 // (The second run fits three waves per SIMD without spilling - 167 registers against 171 when left alone - and
 // gains from the third: subtraction_outside 4K 57.9 -> 52.3 ms together with the empty shade launches left out.  The
 // first run held to three waves spills 22 registers and loses: 53.9 ms.)
-#define RT_REDO_WAVES 3
+#define RT_REDO_WAVES(F) ((((F) & (RTF_MESH | RTF_WRAP | RTF_MISC)) == 0u) ? 3 : 1)   // (the variant with every feature would spill 264 registers: left alone)
 template <uint32_t F, bool COUNT, bool HOT, bool REDO>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REDO ? RT_REDO_WAVES : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REDO ? RT_REDO_WAVES(F) : 1)))
 k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
     constexpr bool HAS_MESH = (F & RTF_MESH) != 0;
     constexpr bool HAS_CSG = (F & RTF_CSG) != 0;
