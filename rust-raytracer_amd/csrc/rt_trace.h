@@ -1014,12 +1014,14 @@ RT_DEV int exact_tie_order(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j)
     return i > j ? (di < dj ? 1 : 0) : (dj < di ? 0 : 1);
 }
 
-// A workgroup's list of such decisions, in LDS: (query, instance tested, best instance at that moment).  A full list
-// drops further notes (their decisions stand as the 8-ulp rule made them).
-#define RT_TIE_LIST 48u
+// A sub-queue's list of such decisions, in global memory: (query, instance tested, best instance at that moment).
+// A full list drops further notes (their decisions stand as the 8-ulp rule made them, and which notes were dropped
+// depends on the order the lanes arrived in): sized for the seams of a 5000 x 5000 frame under AA, 256 sub-queues x
+// 1024 notes per generation of rays.
+#define RT_TIE_LIST 1024u
 struct TieLog {
-    uint32_t* count;           // LDS: entries noted so far
-    uint32_t* entries;         // LDS: RT_TIE_LIST x 3 words
+    uint32_t* count;           // entries noted so far (null: nothing is noted)
+    uint32_t* entries;         // RT_TIE_LIST x 3 words
     uint32_t query;            // the query the calling lane is working on
     RT_DEV void note(uint32_t i, uint32_t j) {
         const uint32_t at = atomicAdd(count, 1u);

@@ -247,6 +247,22 @@ def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatc
     assert a["counters"]["stack_overflows"] == 0
 
 
+def test_tie_lists_hold_the_seams_of_a_large_frame(device_scene, scene_cache, oracle):
+    """The wall seams of scene_light_1_05 are ties pixel after pixel, and every one of them five more times in the
+    AA pass: at 1024 x 1024 some sub-queues note more than a hundred decisions per generation.  A list that
+    overflowed would leave some to the 8-ulp rule - which ones depending on the order the lanes arrived in - so the
+    frame must be the same twice over and agree with the oracle in every primary hit."""
+    s = scene_cache("scene_light_1_05")
+    ds = device_scene("scene_light_1_05")
+    dim, cam, cfg = small_view(s, 1024, anti_alias=True, seed=1)
+    a = ds.render(dim, cam, cfg)
+    b = ds.render(dim, cam, cfg)
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit_id"], b["hit_id"])
+    want = oracle.render(s, dim, cam, cfg)
+    assert np.array_equal(a["hit_id"], want["hit_id"])
+    assert (np.abs(a["rgb"].astype(int) - want["rgb"].astype(int)).max(axis=2) > 1).mean() <= 1.0 - LSB_FRACTION
+
+
 @pytest.mark.parametrize("name,width", [("glass_monkey", 320), ("many_balls", 160)])
 def test_chain_count_does_not_change_the_frame(name, width, device_scene, scene_cache, monkeypatch):
     """The queue pipeline run as 1, 2 or 4 chains of launches on separate streams: the same frame."""
