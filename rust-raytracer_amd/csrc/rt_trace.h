@@ -1185,7 +1185,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
 // changes hands; returns whether it did.
 template <uint32_t F>
 RT_DEV bool resolve_tie(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j, SceneHit& hit) {
-    if (hit.inst != i && hit.inst != j) return false;              // a nearer surface was found afterwards
+    if (hit.inst != i && hit.inst != j) j = hit.inst;              // j has lost to another surface since (a third one at the same distance, or a nearer one): i meets that one
     const int exact = exact_tie_order<F>(sc, o, d, i, j);
     if (exact < 0) return false;
     const uint32_t want = exact ? i : j;
