@@ -107,23 +107,30 @@ def host_cores():
 
 
 def cpu_baseline(oracle, scene, dim, cam, cfg, label, every):
-    """Time the CPU oracle on every `every`-th row block of the same frame, at the reference's default pool
-    size (8 threads, src/render.rs:20) and, when the host gives this job more, on all of its cores."""
+    """Time the CPU oracle on the same frame, at the reference's default pool size (8 threads, src/render.rs:20) and,
+    when the host gives this job more, on all of its cores: three runs per pool size, each over every
+    (3 * `every`)-th row block starting at a different block, the median of the three reported."""
     cores = host_cores()
     rows = []
     for threads in sorted({8, cores}):
-        c = cfg.copy()
-        c.num_threads = threads
-        c.rank, c.nranks, c.tile_rows = 1, every, TILE_ROWS
-        t0 = time.time()
-        out = oracle.render(scene, dim, cam, c, want_aux=True, faithful_cost=True)
-        dt = time.time() - t0
-        rays = out["counters"]["rays_total"]
-        rows.append({"threads": threads, "Mrays/s": rays / dt / 1e6, "rays": rays, "seconds": dt})
+        runs = []
+        for k in range(3):
+            c = cfg.copy()
+            c.num_threads = threads
+            c.rank, c.nranks, c.tile_rows = 1 + k * every, 3 * every, TILE_ROWS
+            t0 = time.time()
+            out = oracle.render(scene, dim, cam, c, want_aux=True, faithful_cost=True)
+            dt = time.time() - t0
+            rays = out["counters"]["rays_total"]
+            runs.append({"Mrays/s": rays / dt / 1e6, "rays": rays, "seconds": dt})
+        med = sorted(runs, key=lambda r: r["Mrays/s"])[1]
+        rows.append({"threads": threads, "Mrays/s": med["Mrays/s"], "rays": med["rays"], "seconds": med["seconds"],
+                     "all": [round(r["Mrays/s"], 3) for r in runs]})
     first = rows[0]
     return {"value": first["Mrays/s"], "unit": "Mrays/s", "cores": first["threads"], "kind": "port",
             "host_cores": cores, "machine_cpus": os.cpu_count(), "runs": rows,
-            "sample": f"{label}, every {every}th {TILE_ROWS}-row block (+1-row AA halo): {first['rays']} rays in {first['seconds']:.1f} s; "
+            "sample": f"{label}: median of three runs, each over every {3 * every}th {TILE_ROWS}-row block (+1-row AA halo) from a different "
+                      f"first block ({first['rays']} rays in {first['seconds']:.1f} s in the median run); "
                       f"C++ restatement of the reference CPU path incl. its per-hit 4x4 inverse, {first['threads']} threads "
                       f"(reference default), not the Rust binary"}
 
