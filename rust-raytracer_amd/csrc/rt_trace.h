@@ -222,7 +222,9 @@ RT_DEV int faced_hits(const DScene& sc, const DFaced& f, const LRay& r, double t
         bool hit = f.base_is_triangle ? tri_hit(sc.tris[f.base_tri], fr, tf) : rect_hit(f.base_w, f.base_h, fr, tf);
         if (!hit) continue;
         d3 p = xf_point(f.face[i].l2w, fr.o + (tf * fr.d));
-        double dist = length(p - r.o);                           // intersect.rs:34
+        // (the reference measures from the ray's origin as it comes back through the face's matrix, not from the origin
+        // it started with: Intersect::transform, intersect.rs:31-34, on the face-space intersect of cube.rs:44-47)
+        double dist = length(p - xf_point(f.face[i].l2w, fr.o));
         if (!(dist >= RT_MIN_DISTANCE)) continue;
         if (n == 0) { t[0] = dist; face[0] = i; n = 1; }
         else {
@@ -985,6 +987,9 @@ RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t le
             Details dt;
             faced_details(sc, sc.faced[p.ref], r, c[0].a, dt);
             hit = dt.p;
+            double fs, finv_s;                                     // ... and so does the ray's origin, which the levels above measure from
+            const DXform& fx = sc.faced[p.ref].face[c[0].a];
+            org = xf_point(fx.l2w, to_local(fx, r.o, r.d, fs, finv_s).o);
         }
     }
     for (uint32_t k = ch.len - 1u; k > level; --k) {
