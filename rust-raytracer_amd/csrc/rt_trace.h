@@ -96,12 +96,16 @@ RT_DEV bool replaces_hit(double t, uint32_t i, double best, uint32_t best_i, boo
     return t < best;
 }
 
-// world/parent ray → local ray; returns s = |M_lin d| (local length of a unit parent step)
+// world/parent ray → local ray; returns s = |M_lin d| (local length of a unit parent step).  Under a uniform scale
+// the length is the matrix's own, known beforehand: it stands in for the square root and the division of the
+// reference's renormalisation (geometry/ray.rs:90-97) at a cost of one unit in the last place of the direction.
+// EXACT takes the reference's arithmetic instead: the pass that decides ties needs every bit.
+template <bool EXACT = false>
 RT_DEV LRay to_local(const DXform& x, d3 o, d3 d, double& s, double& inv_s) {
     LRay r;
     r.o = xf_point(x.w2l, o);
     d3 v = xf_vector(x.w2l, d);
-    if (x.uniform_inv_s != 0.0) { inv_s = x.uniform_inv_s; s = x.uniform_s; }
+    if (!EXACT && x.uniform_inv_s != 0.0) { inv_s = x.uniform_inv_s; s = x.uniform_s; }
     else { s = length(v); inv_s = 1.0 / s; }
     r.d = v * inv_s;
     return r;
@@ -213,11 +217,12 @@ RT_DEV bool poly_hit(const DScene& sc, const DPoly& pl, const LRay& r, double& t
 // ------------------------------------------------------------------ Cube / Tetrahedron (src/primitive/cube.rs:40-69, 131-163)
 // Faces are tested in the reference's order; the first two valid faces are kept, ordered
 // by distance in the solid's space, and the loop stops at the second.
+template <bool EXACT = false>
 RT_DEV int faced_hits(const DScene& sc, const DFaced& f, const LRay& r, double t[2], uint32_t face[2]) {
     int n = 0;
     for (uint32_t i = 0; i < f.nfaces; ++i) {
         double s, inv_s;
-        LRay fr = to_local(f.face[i], r.o, r.d, s, inv_s);
+        LRay fr = to_local<EXACT>(f.face[i], r.o, r.d, s, inv_s);
         double tf;
         bool hit = f.base_is_triangle ? tri_hit(sc.tris[f.base_tri], fr, tf) : rect_hit(f.base_w, f.base_h, fr, tf);
         if (!hit) continue;
@@ -236,9 +241,10 @@ RT_DEV int faced_hits(const DScene& sc, const DFaced& f, const LRay& r, double t
     }
     return n;
 }
+template <bool EXACT = false>
 RT_DEV void faced_details(const DScene& sc, const DFaced& f, const LRay& r, uint32_t i, Details& o) {
     double s, inv_s, tf = 0.0;
-    LRay fr = to_local(f.face[i], r.o, r.d, s, inv_s);
+    LRay fr = to_local<EXACT>(f.face[i], r.o, r.d, s, inv_s);
     Details b;
     if (f.base_is_triangle) { tri_hit(sc.tris[f.base_tri], fr, tf); tri_details(sc.tris[f.base_tri], fr, tf, b); }
     else { rect_hit(f.base_w, f.base_h, fr, tf); rect_details(f.base_w, f.base_h, fr, tf, b); }
@@ -979,18 +985,26 @@ RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t le
     }
     Cand c[2];
     Work<false> none;
-    if (basic_hits<F, false>(sc, p, r, INFINITY, c, none) == 0) return false;
-    dist = c[0].t;
-    d3 hit = r.o + (c[0].t * r.d), org = r.o;
-    if constexpr (F & RTF_FACED) {
-        if (p.kind == DP_FACED) {                                  // a cube's hit point comes back through its face's matrix (cube.rs:44-47)
-            Details dt;
-            faced_details(sc, sc.faced[p.ref], r, c[0].a, dt);
+    bool faced = false;
+    if constexpr (F & RTF_FACED) faced = p.kind == DP_FACED;
+    d3 hit, org;
+    if (faced) {
+        if constexpr (F & RTF_FACED) {                             // a cube's faces, with the ray renormalised in each face's frame as the reference does
+            double t[2]; uint32_t fc[2];
+            const DFaced& f = sc.faced[p.ref];
+            if (faced_hits<true>(sc, f, r, t, fc) == 0) return false;
+            dist = t[0];
+            Details dt;                                            // the hit point comes back through the face's matrix (cube.rs:44-47)
+            faced_details<true>(sc, f, r, fc[0], dt);
             hit = dt.p;
             double fs, finv_s;                                     // ... and so does the ray's origin, which the levels above measure from
-            const DXform& fx = sc.faced[p.ref].face[c[0].a];
-            org = xf_point(fx.l2w, to_local(fx, r.o, r.d, fs, finv_s).o);
+            const DXform& fx = f.face[fc[0]];
+            org = xf_point(fx.l2w, to_local<true>(fx, r.o, r.d, fs, finv_s).o);
         }
+    } else {
+        if (basic_hits<F, false>(sc, p, r, INFINITY, c, none) == 0) return false;
+        dist = c[0].t;
+        hit = r.o + (c[0].t * r.d); org = r.o;
     }
     for (uint32_t k = ch.len - 1u; k > level; --k) {
         const DNodeXf& x = sc.node_xf[sc.chain_nodes[ch.first + k]];
