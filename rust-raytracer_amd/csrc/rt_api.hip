@@ -269,12 +269,13 @@ int rt_scene_create_with(const RtSceneDesc* desc, int device, uint32_t ingest, R
     d.has_clear_to_light = 0;
     for (const DInstance& in : fs.instances) if (in.is_root & RT_INST_CLEAR_TO_LIGHT) d.has_clear_to_light = 1;
     {
-        uint32_t chainable = 0;
+        uint32_t chainable = 0, edged = 0;
         for (const DInstance& in : fs.instances) {
             const DPrim& p = fs.prims[in.prim];
             if (p.kind != DP_MESH && p.kind != DP_CSG && !p.wrap) ++chainable;
+            if ((p.kind == DP_TRIANGLE || p.kind == DP_POLYGON || p.kind == DP_POLYHEDRON) && !p.wrap) ++edged;   // (one is enough: a ray along its edge, resolve_doubt)
         }
-        s->ties_possible = chainable >= 2;
+        s->ties_possible = chainable >= 2 || edged >= 1;
     }
     {   // (RT_WF_SHADE_CLS=0: every list on the general kernel, for tests that compare the two)
         const char* e = std::getenv("RT_WF_SHADE_CLS");

@@ -186,6 +186,29 @@ RT_DEV bool tri_hit(const DTri& tr, const LRay& r, double& t) {        // :141-1
     }
     return false;
 }
+// Cand::b of a primitive tested with DOUBTING: one of its inside tests came out within rounding of zero (the ray
+// runs along an edge), so the last place of the ray's coordinates in the primitive's space decided hit or miss.
+#define RT_CAND_DOUBT 0x40000000u
+RT_DEV bool doubtful(double value, d3 a, d3 b) { return value * value <= 1e-20 * (dot(a, a) * dot(b, b)); }
+// tri_hit, also saying whether the verdict hung on rounding
+RT_DEV bool tri_hit_doubt(const DTri& tr, const LRay& r, double& t, bool& doubt) {
+    d3 n = ld3(tr.n);
+    double origin_dot = dot(n, r.o - ld3(tr.v));
+    double direction_dot = dot(n, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        bool inside = true;
+        for (int k = 0; k < 3; ++k) {
+            const d3 e = ld3(tr.e + 3 * k), pv = p - ld3(tr.v + 3 * k);
+            const double a = dot(cross(e, pv), n);
+            doubt = doubt || doubtful(a, e, pv);
+            inside = inside && a >= 0.0;
+        }
+        if (inside) { t = hit_distance; return true; }
+    }
+    return false;
+}
 RT_DEV void tri_details(const DTri& tr, const LRay& r, double t, Details& o) {   // :129-136, :158-159
     o.p = r.o + (t * r.d);
     double side_a = length(o.p - ld3(tr.v)), side_b = length(o.p - ld3(tr.v + 3));
@@ -210,6 +233,27 @@ RT_DEV bool poly_hit(const DScene& sc, const DPoly& pl, const LRay& r, double& t
             if (!(dot(cross(ld3(E + 3 * i), p - ld3(V + 3 * i)), n) >= 0.0)) return false;
         t = hit_distance;
         return true;
+    }
+    return false;
+}
+
+RT_DEV bool poly_hit_doubt(const DScene& sc, const DPoly& pl, const LRay& r, double& t, bool& doubt) {
+    d3 n = ld3(pl.n);
+    const double* V = sc.points + 3 * (size_t)pl.first_vertex;
+    const double* E = sc.points + 3 * (size_t)pl.first_edge;
+    double origin_dot = dot(n, r.o - ld3(V));
+    double direction_dot = dot(n, r.d);
+    double hit_distance = -origin_dot / direction_dot;
+    if (hit_distance > RT_MIN_DISTANCE) {
+        d3 p = r.o + (hit_distance * r.d);
+        bool inside = true;
+        for (uint32_t i = 0; i < pl.count; ++i) {
+            const d3 e = ld3(E + 3 * i), pv = p - ld3(V + 3 * i);
+            const double a = dot(cross(e, pv), n);
+            doubt = doubt || doubtful(a, e, pv);
+            inside = inside && a >= 0.0;
+        }
+        if (inside) { t = hit_distance; return true; }
     }
     return false;
 }
@@ -271,6 +315,27 @@ RT_DEV bool polyhedron_hit(const DScene& sc, const DPrim& ph, const LRay& r, dou
         for (uint32_t k = 1; k < ph.count; ++k) {
             const double* q = sc.prims[ph.ref + (k + i) % ph.count].p;
             if (dot(ld3(q) - p, ld3(q + 3)) < 0.0) { inside = false; break; }
+        }
+        if (!inside) continue;
+        if (!found || ti < t) { t = ti; plane = i; found = true; }
+    }
+    return found;
+}
+
+RT_DEV bool polyhedron_hit_doubt(const DScene& sc, const DPrim& ph, const LRay& r, double& t, uint32_t& plane, bool& doubt) {
+    bool found = false;
+    for (uint32_t i = 0; i < ph.count; ++i) {
+        const double* pp = sc.prims[ph.ref + i].p;
+        double ti;
+        if (!plane_hit(pp, r, ti)) continue;
+        d3 p = r.o + (ti * r.d);
+        bool inside = true;
+        for (uint32_t k = 1; k < ph.count; ++k) {
+            const double* q = sc.prims[ph.ref + (k + i) % ph.count].p;
+            const d3 qp = ld3(q) - p, qn = ld3(q + 3);
+            const double a = dot(qp, qn);
+            doubt = doubt || doubtful(a, qp, qn);
+            inside = inside && !(a < 0.0);
         }
         if (!inside) continue;
         if (!found || ti < t) { t = ti; plane = i; found = true; }
@@ -655,8 +720,21 @@ RT_DEV void mesh_walk_batch(const DScene& sc, uint8_t* lane_mem, uint32_t live_m
 
 // ------------------------------------------------------------------ basic (non-composite) primitives
 // get_all_intersects of a primitive without wrappers: up to two hits, ascending.
-template <uint32_t F, bool COUNT>
+// DOUBTING: a triangle, polygon or polyhedron also reports in c[0].b (RT_CAND_DOUBT, hit or miss) whether its verdict
+// hung on rounding.
+template <uint32_t F, bool COUNT, bool DOUBTING = false>
 RT_DEV int basic_hits(const DScene& sc, const DPrim& p, const LRay& r, double tmax_closest, Cand c[2], Work<COUNT>& wk) {
+    if constexpr (DOUBTING && (F & RTF_MISC) != 0) {
+        if (p.kind == DP_TRIANGLE || p.kind == DP_POLYGON || p.kind == DP_POLYHEDRON) {
+            bool doubt = false, hit;
+            c[0].a = 0;
+            if (p.kind == DP_TRIANGLE) hit = tri_hit_doubt(sc.tris[p.ref], r, c[0].t, doubt);
+            else if (p.kind == DP_POLYGON) hit = poly_hit_doubt(sc, sc.polys[p.ref], r, c[0].t, doubt);
+            else hit = polyhedron_hit_doubt(sc, p, r, c[0].t, c[0].a, doubt);
+            c[0].b = doubt ? RT_CAND_DOUBT : 0u;
+            return hit ? 1 : 0;
+        }
+    }
     switch (p.kind) {
         case DP_SPHERE: {
             double t[2]; uint32_t w[2];
@@ -971,8 +1049,10 @@ RT_DEV void csg_details(const DScene& sc, const LRay& r, const Cand& c, Details&
 // (geometry/intersect.rs:31-45).  `level` is the node at which the comparison takes place: the instance's own
 // node (the primitive's own distance) or an ancestor of it.  False when the primitive is of a kind this does
 // not cover (meshes, composite shapes, wrapped primitives), or is not hit by the ray that went down the chain.
+// level -1: the distance the scene's caller sees, above the root node's own transform.  `cand` (optional): the hit
+// in the primitive's space, as the loop over instances would record it.
 template <uint32_t F>
-RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t level, double& dist) {
+RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, int level, double& dist, Cand* cand = nullptr) {
     const DChain ch = sc.inst_chain[i];
     const DPrim& p = sc.prims[sc.instances[i].prim];
     if (p.kind == DP_MESH || p.kind == DP_CSG || ((F & RTF_WRAP) && p.wrap)) return false;
@@ -994,6 +1074,7 @@ RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t le
             const DFaced& f = sc.faced[p.ref];
             if (faced_hits<true>(sc, f, r, t, fc) == 0) return false;
             dist = t[0];
+            if (cand) { cand->t = t[0]; cand->a = fc[0]; cand->b = 0; }
             Details dt;                                            // the hit point comes back through the face's matrix (cube.rs:44-47)
             faced_details<true>(sc, f, r, fc[0], dt);
             hit = dt.p;
@@ -1004,9 +1085,10 @@ RT_DEV bool chain_distance(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t le
     } else {
         if (basic_hits<F, false>(sc, p, r, INFINITY, c, none) == 0) return false;
         dist = c[0].t;
+        if (cand) *cand = c[0];
         hit = r.o + (c[0].t * r.d); org = r.o;
     }
-    for (uint32_t k = ch.len - 1u; k > level; --k) {
+    for (int k = (int)ch.len - 1; k > level; --k) {
         const DNodeXf& x = sc.node_xf[sc.chain_nodes[ch.first + k]];
         hit = xf_point(x.trans, hit);
         org = xf_point(x.trans, org);
@@ -1027,7 +1109,7 @@ RT_DEV int exact_tie_order(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j)
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {                                  // (one copy of the code for both: this path is rare, its registers are not)
         double dk;
-        if (!chain_distance<F>(sc, o, d, k ? j : i, common - 1u, dk)) return -1;
+        if (!chain_distance<F>(sc, o, d, k ? j : i, (int)common - 1, dk)) return -1;
         if (k) dj = dk; else di = dk;
     }
     return i > j ? (di < dj ? 1 : 0) : (dj < di ? 0 : 1);
@@ -1057,7 +1139,8 @@ struct SceneHit {
 
 // WITH_CSG = false: composite shapes are not evaluated; a composite whose bounding box the ray reaches is
 // reported in *deferred (bit min(root index, 31)) for the caller to answer elsewhere, and counts as a miss here.
-template <uint32_t F, bool COUNT, bool WITH_CSG = true>
+// DOUBTING: see basic_hits; the caller clears c.b beforehand and finds RT_CAND_DOUBT there afterwards, hit or miss.
+template <uint32_t F, bool COUNT, bool WITH_CSG = true, bool DOUBTING = false>
 RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, double tmax_local, Cand& c, Work<COUNT>& wk, uint32_t* deferred = nullptr) {
     if constexpr (F & RTF_CSG) {
         if (p.kind == DP_CSG) {
@@ -1080,8 +1163,10 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
     Cand cc[2];
     // an un-wrapped mesh may prune by the best distance so far; wrapped primitives must see their true closest hit
     bool wrapped = (F & RTF_WRAP) && p.wrap;
-    int n = basic_hits<F, COUNT>(sc, p, lr, wrapped ? INFINITY : tmax_local, cc, wk);
-    if (n == 0) return false;
+    if constexpr (DOUBTING) cc[0].b = 0;
+    int n = basic_hits<F, COUNT, DOUBTING>(sc, p, lr, wrapped ? INFINITY : tmax_local, cc, wk);
+    if constexpr (DOUBTING) { if (wrapped) cc[0].b &= ~RT_CAND_DOUBT; }
+    if (n == 0) { if constexpr (DOUBTING) c.b = cc[0].b & RT_CAND_DOUBT; return false; }
     c = cc[0];
     if constexpr (F & RTF_WRAP) { if (p.wrap) return wrap_closest<F>(sc, p, lr, c); }
     return true;
@@ -1099,12 +1184,16 @@ RT_DEV bool prim_closest(const DScene& sc, const DPrim& p, const LRay& lr, doubl
 // winner among equal distances: the earlier instance, kept here by an explicit tie rule.
 // `ties` (optional): closest-hit decisions between two instances whose distances differ by rounding only are noted
 // there (TieLog), for the caller to decide again the reference's way once the query is through.
-template <uint32_t F, bool COUNT, bool SKIP_MESH, bool WITH_CSG = true, class TIES = TieLog>
-RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk, uint32_t* deferred = nullptr, TIES* ties = nullptr) {
+// DOUBTING: an instance whose verdict hung on rounding (basic_hits) is noted as (i, i).  EXCLUDING: the `nexclude`
+// instances listed in `exclude` are left out (the query taken again without the instances the second look judges).
+template <uint32_t F, bool COUNT, bool SKIP_MESH, bool WITH_CSG = true, class TIES = TieLog, bool DOUBTING = false, bool EXCLUDING = false>
+RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_distance, SceneHit& hit, Work<COUNT>& wk, uint32_t* deferred = nullptr, TIES* ties = nullptr,
+                        const uint32_t* exclude = nullptr, uint32_t nexclude = 0u) {
     bool found = false;
     double best = any ? max_distance : INFINITY;
     // one instance; returns true when an any-hit query is settled
     auto visit = [&](uint32_t i) -> bool {
+        if constexpr (EXCLUDING) { for (uint32_t k = 0; k < nexclude; ++k) if (i == exclude[k]) return false; }
         const DInstance& in = sc.instances[i];
         const DPrim& p = sc.prims[in.prim];
         if constexpr (SKIP_MESH) { if (p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap)) return false; }
@@ -1124,6 +1213,7 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
         double s, inv_s;
         LRay lr = to_local(in.x, o, d, s, inv_s);
         Cand c;
+        if constexpr (DOUBTING) c.b = 0;
         bool got;
         bool direct_mesh = false;
         if constexpr ((F & RTF_MESH) && !SKIP_MESH) direct_mesh = p.kind == DP_MESH && !((F & RTF_WRAP) && p.wrap);
@@ -1135,7 +1225,11 @@ RT_DEV bool trace_scene(const DScene& sc, d3 o, d3 d, bool any, double max_dista
                 if (any) return got;
             }
         } else {
-            got = prim_closest<F, COUNT, WITH_CSG>(sc, p, lr, any ? INFINITY : best * s, c, wk, deferred);
+            got = prim_closest<F, COUNT, WITH_CSG, DOUBTING>(sc, p, lr, any ? INFINITY : best * s, c, wk, deferred);
+            if constexpr (DOUBTING) {
+                if ((c.b & RT_CAND_DOUBT) && ties && ties->count) ties->note(i, i);   // (looked at again by resolve_doubt, or as a shadow test's verdict)
+                c.b &= ~RT_CAND_DOUBT;
+            }
             if (any) return got && ((in.is_root & RT_INST_ROOT) ? c.t <= max_distance * s : c.t < max_distance * s);
         }
         if (!got) return false;
@@ -1218,6 +1312,54 @@ RT_DEV bool resolve_tie(const DScene& sc, d3 o, d3 d, uint32_t i, uint32_t j, Sc
     if (!prim_closest<F, false, false>(sc, sc.prims[in.prim], lr, INFINITY, c, none, &unused)) return false;
     hit.inst = want; hit.c = c; hit.t = c.t * inv_s;
     return true;
+}
+
+// A query's noted doubts, looked at again: the loop's verdict on each of the instances in `doubted` (triangles,
+// polygons or polyhedra met along an edge; ascending, at most RT_DOUBT_SET of them) hung on the last place of the
+// ray in the primitive's space, which the loop reaches through one composed matrix and the reference through its
+// chain of nodes.  The chain's verdicts stand: the query is taken again without those instances, and each of them
+// that the chain's ray hits then enters against the answer the reference's way (exact_tie_order).  The result does
+// not depend on the order in which the notes were made.  `found` / `hit`: the query's answer, replaced.
+#define RT_DOUBT_SET 4u
+template <uint32_t F>
+RT_DEV void resolve_doubts(const DScene& sc, d3 o, d3 d, const uint32_t* doubted, uint32_t n, SceneHit& hit, bool& found) {
+    const SceneHit before = hit;
+    const bool had = found;
+    SceneHit again;
+    again.t = 0.0; again.inst = 0; again.c.t = 0.0; again.c.a = 0; again.c.b = 0;
+    Work<false> none;
+    uint32_t unused = 0;
+    found = trace_scene<F, false, (F & RTF_MESH) != 0, true, TieLog, false, true>(sc, o, d, false, 0.0, again, none, &unused, nullptr, doubted, n);
+    if (found) hit = again;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t i = doubted[k];
+        double world_t = 0.0;
+        Cand ce;
+        ce.t = 0.0; ce.a = 0; ce.b = 0;
+        if (!chain_distance<F>(sc, o, d, i, -1, world_t, &ce)) continue;
+        bool wins = !found;
+        if (found) {
+            const int order = exact_tie_order<F>(sc, o, d, i, hit.inst);
+            wins = order < 0 ? replaces_hit(world_t, i, hit.t, hit.inst, true) : order == 1;
+        }
+        if (wins) { hit.inst = i; hit.c = ce; hit.t = world_t; found = true; }
+    }
+    // (the same instance and face as the loop's answer: its own numbers stay, which the shading that follows was made for)
+    if (found && had && hit.inst == before.inst && hit.c.a == before.c.a) hit = before;
+}
+// ... and a shadow test's: does anything but the doubted instances lie before the light, or one of them by its chain?
+template <uint32_t F>
+RT_DEV bool resolve_shadow_doubts(const DScene& sc, d3 o, d3 d, double limit, const uint32_t* doubted, uint32_t n) {
+    SceneHit other;
+    other.t = 0.0; other.inst = 0; other.c.t = 0.0; other.c.a = 0; other.c.b = 0;
+    Work<false> none;
+    uint32_t unused = 0;
+    if (trace_scene<F, false, (F & RTF_MESH) != 0, true, TieLog, false, true>(sc, o, d, true, limit, other, none, &unused, nullptr, doubted, n)) return true;
+    for (uint32_t k = 0; k < n; ++k) {
+        double world_t;
+        if (chain_distance<F>(sc, o, d, doubted[k], -1, world_t) && ((sc.instances[doubted[k]].is_root & RT_INST_ROOT) ? world_t <= limit : world_t < limit)) return true;
+    }
+    return false;
 }
 
 // A lane's own notes, for a kernel whose lanes decide their ties themselves right after the query (the persistent

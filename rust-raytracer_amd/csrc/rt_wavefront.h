@@ -391,9 +391,12 @@ k_wf_analytic(DScene gsc, DRenderParams rp, WfArgs a) {
         SceneHit h;
         h.inst = 0; h.c.t = 0.0; h.c.a = 0; h.c.b = 0;
         uint32_t deferred = 0;
+        // (triangles, polygons and polyhedra met along an edge are noted as well, by shadow tests too - bit 31 of the
+        // query - : k_wf_ties takes the reference's verdict on them)
+        constexpr bool DOUBTING = !REDO && (F & RTF_MISC) != 0;
         TieLog ties;                                                  // (a null list: nothing is noted - shadow tests, the second run)
-        ties.count = (REDO || shadow) ? nullptr : tie_count; ties.entries = tie_entries; ties.query = q;
-        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG>(sc, o, d, shadow, max_distance, h, wk, &deferred, &ties);
+        ties.count = (REDO || (shadow && !DOUBTING)) ? nullptr : tie_count; ties.entries = tie_entries; ties.query = shadow ? (q | 0x80000000u) : q;
+        bool found = trace_scene<F, COUNT, HAS_MESH, REDO || !HAS_CSG, TieLog, DOUBTING>(sc, o, d, shadow, max_distance, h, wk, &deferred, &ties);
         if constexpr (HAS_CSG && !REDO) {
             if (deferred && !(shadow && found)) {                     // (an occluded shadow test needs no composite any more)
                 wk = wk_before; cam = cam_before;                     // its record is written, and its work counted, by the second run
@@ -494,15 +497,54 @@ k_wf_ties(DScene sc, DRenderParams rp, WfArgs a) {
         const uint32_t q = tie_entries[3 * e];
         bool first = true;
         for (uint32_t k = 0; k < e; ++k) first = first && tie_entries[3 * k] != q;
-        if (!first || !a.rjobs.U(cap, JQ_FOUND, q)) continue;
+        if (!first) continue;
+        // (i, i): instance i was met along an edge; a query's doubted instances are judged together (resolve_doubts), before its
+        // ties.  Left as the loop decided them in scenes with meshes, whose walk lists have been made with the loop's distances by now.
+        const bool doubts = (F & RTF_MISC) != 0 && sc.num_mesh_instances == 0u;
+        uint32_t doubted[RT_DOUBT_SET];
+        uint32_t nd = 0;
+        if constexpr ((F & RTF_MISC) != 0) {
+            if (doubts) {
+                for (uint32_t k = e; k < nt; ++k) {
+                    if (tie_entries[3 * k] != q || tie_entries[3 * k + 1] != tie_entries[3 * k + 2]) continue;
+                    const uint32_t ti = tie_entries[3 * k + 1];
+                    uint32_t at = 0;                              // ascending, each once
+                    while (at < nd && doubted[at] < ti) ++at;
+                    if ((at < nd && doubted[at] == ti) || nd == RT_DOUBT_SET) continue;
+                    for (uint32_t m = nd; m > at; --m) doubted[m] = doubted[m - 1];
+                    doubted[at] = ti; ++nd;
+                }
+            }
+        }
+        if (q & 0x80000000u) {                                        // a shadow test: the verdict with the noted instances judged by their chains
+            if constexpr ((F & RTF_MISC) != 0) {
+                if (nd == 0u) continue;
+                const uint32_t qs = q & 0x7FFFFFFFu;
+                const bool before = a.sjobs.U(cap, JQ_FOUND, qs) != 0u;
+                const bool verdict = resolve_shadow_doubts<F>(sc, a.shadows.ld3(cap, SQ_O, qs), a.shadows.ld3(cap, SQ_D, qs), a.shadows.F(cap, SQ_DIST, qs), doubted, nd);
+                if (verdict != before) {
+                    a.sjobs.U(cap, JQ_FOUND, qs) = verdict ? 1u : 0u;
+                    a.sjobs.U(cap, JQ_FLAGS, qs) = 1u | (verdict ? 2u : 0u);
+                }
+            }
+            continue;
+        }
+        bool found = a.rjobs.U(cap, JQ_FOUND, q) != 0u;
         const d3 o = a.rays.ld3(cap, RQ_O, q), d = a.rays.ld3(cap, RQ_D, q);
         SceneHit h;
         h.t = a.rjobs.F(cap, JQ_T, q); h.inst = a.rjobs.U(cap, JQ_INST, q);
         h.c.t = a.rjobs.F(cap, JQ_CT, q); h.c.a = a.rjobs.U(cap, JQ_CA, q); h.c.b = a.rjobs.U(cap, JQ_CB, q);
         bool changed = false;
-        for (uint32_t k = e; k < nt; ++k)
-            if (tie_entries[3 * k] == q) changed = resolve_tie<F>(sc, o, d, tie_entries[3 * k + 1], tie_entries[3 * k + 2], h) || changed;
+        if constexpr ((F & RTF_MISC) != 0) {
+            if (nd) { resolve_doubts<F>(sc, o, d, doubted, nd, h, found); changed = true; }
+        }
+        for (uint32_t k = e; k < nt; ++k) {
+            if (tie_entries[3 * k] != q) continue;
+            const uint32_t ti = tie_entries[3 * k + 1], tj = tie_entries[3 * k + 2];
+            if (ti != tj && found) changed = resolve_tie<F>(sc, o, d, ti, tj, h) || changed;
+        }
         if (changed) {
+            a.rjobs.U(cap, JQ_FOUND, q) = found ? 1u : 0u;
             a.rjobs.F(cap, JQ_T, q) = h.t; a.rjobs.F(cap, JQ_CT, q) = h.c.t;
             a.rjobs.U(cap, JQ_INST, q) = h.inst; a.rjobs.U(cap, JQ_CA, q) = h.c.a; a.rjobs.U(cap, JQ_CB, q) = h.c.b;
         }

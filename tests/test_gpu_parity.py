@@ -14,17 +14,18 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 LSB_FRACTION = 0.999     # >= 99.9 % of pixels within 1 LSB per channel
 PSNR_DB = 50.0
 
-# Two surfaces of different nodes at one distance (coplanar touching faces, oversized walls seen along their seam):
-# both schedules note such decisions and take them again the reference's way, through the per-level chain of
-# transforms (k_wf_ties in the queue pipeline, right after the query in the persistent kernel), so those pixels agree
-# with the oracle: scene_light_1_05 (130 seam pixels in an earlier build), refraction_03 (12), the nested cubes of
-# child_transform_test_1 and subdivision_light need no allowance any more.
-# What is left are decisions *inside* one primitive on rays that graze it exactly - the reference's +1.0 pixel
-# offset puts row H/2-1 and column W/2-1 on the optical axis, so a camera aimed at a symmetric solid shoots a
-# row of rays along its edges - where the last ulp of the ray in the primitive's space decides hit or miss, and
-# the composed transform of the flat instance loop is not the reference's chain of per-level ones:
-TIE_SCENES = {"octahedron_basic": 4, "octahedron_basic_02": 5,   # rays along the octahedron's edges (polyhedron.rs:99-107: inside all other planes?)
-              "triangle_basic": 2}                               # ... along the triangle's edge (plane.rs:141-164)
+# Decisions that hang on the last place of a distance are taken again the reference's way, through its per-level chain
+# of transforms (k_wf_ties in the queue pipeline, right after the query in the persistent kernel): two surfaces of
+# different nodes at one distance (coplanar touching faces, oversized walls seen along their seam: scene_light_1_05 had
+# 130 such pixels, refraction_03 12), and rays that run along an edge of a triangle, polygon or polyhedron - the
+# reference's +1.0 pixel offset puts row H/2-1 and column W/2-1 on the optical axis, so a camera aimed at a symmetric
+# solid shoots a row of rays along its edges (octahedron_basic had 4 differing hit ids, octahedron_basic_02 5,
+# triangle_basic 2).  Every primary hit id of every scene now equals the oracle's: no scene has an allowance.
+# What is left is one pixel of octahedron_basic: a shadow test along an edge, starting from a hit point on the floor
+# that comes through one composed matrix, not the chain, and can itself be one unit in the last place off; its AA mask
+# and ray counts may differ by that pixel's.
+TIE_SCENES = {}
+EDGE_SHADOW_SCENES = {"octahedron_basic"}
 # Scenes whose colour is ill-conditioned on a few pixels, so that the last-place differences between the flattened and the
 # per-level transforms show: (fraction of pixels within 1 LSB, PSNR)
 #   plane_texture     an infinite textured plane seen at grazing angles: thousands of units away the texel is decided by
@@ -93,15 +94,16 @@ def test_scene_matches_oracle_with_aa(name, device_scene, scene_cache, oracle):
     want = oracle.render(s, dim, cam, cfg)
     slack = TIE_SCENES.get(name, 0)
     check(got, want, name, hit_slack=slack)
-    if slack == 0 and name not in LOOSE_SCENES:
+    exact = slack == 0 and name not in LOOSE_SCENES and name not in EDGE_SHADOW_SCENES
+    if exact:
         assert np.array_equal(got["aa_mask"], want["aa_mask"]), name
     # the unit of the benchmark metric is counted identically on both sides
     assert got["counters"]["rays_primary"] == want["counters"]["rays_primary"], name
-    if slack == 0 and name not in LOOSE_SCENES:
+    if exact:
         assert got["counters"]["rays_aa"] == want["counters"]["rays_aa"], name
     total_g, total_o = got["counters"]["rays_total"], want["counters"]["rays_total"]
     # (a tie pixel that goes the other way can flip an AA flag, and with it aa_rays whole ray trees)
-    assert abs(total_g - total_o) <= max(2, total_o // (200 if slack else 500)), (name, total_g, total_o)
+    assert abs(total_g - total_o) <= max(2, total_o // (200 if not exact else 500)), (name, total_g, total_o)
 
 
 @pytest.mark.parametrize("name", ["basic_setup_scene", "light_room", "glass_monkey", "many_balls", "many_balls_forest",
@@ -247,7 +249,8 @@ def test_both_schedules_agree(name, width, device_scene, scene_cache, monkeypatc
     assert a["counters"]["stack_overflows"] == 0
 
 
-@pytest.mark.parametrize("name,anti_alias", [("scene_light_1_05", True), ("child_transform_test_1", False)])
+@pytest.mark.parametrize("name,anti_alias", [("scene_light_1_05", True), ("child_transform_test_1", False), ("octahedron_basic", True),
+                                             ("octahedron_basic_02", True), ("polygon_basic", True)])
 def test_ties_of_a_large_frame(name, anti_alias, device_scene, scene_cache, oracle):
     """The wall seams of scene_light_1_05 are ties pixel after pixel, and every one of them five more times in the
     AA pass: at 1024 x 1024 some sub-queues note more than a hundred decisions per generation.  A list that
@@ -255,7 +258,8 @@ def test_ties_of_a_large_frame(name, anti_alias, device_scene, scene_cache, orac
     frame must be the same twice over and agree with the oracle in every primary hit.  The nested cubes of
     child_transform_test_1 share whole faces: thousands of ties at this size, each decided by one unit in the last
     place of a distance, which only the reference's own arithmetic reproduces (a cube's ray renormalised in every
-    face's frame, its hit measured from the origin as it comes back through the face's matrix)."""
+    face's frame, its hit measured from the origin as it comes back through the face's matrix).  The octahedra and
+    the polygon stand on the optical axis: a row and a column of rays run along their edges, noted as doubts."""
     s = scene_cache(name)
     ds = device_scene(name)
     dim, cam, cfg = small_view(s, 1024, anti_alias=anti_alias, seed=1)
