@@ -11,7 +11,7 @@ render = importlib.import_module("rust-raytracer_amd.render")
 from oracle import binding as oracle
 
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
-for name in sys.argv[2:] or ["scene_light_1_05", "refraction_03", "child_transform_test_1"]:
+for name in sys.argv[2:] or ["scene_light_1_05", "refraction_03", "child_transform_test_1", "octahedron_basic_02", "polygon_basic"]:
     s = scenes.Scene(name)
     h = max(3, int(round(width * s.dim.height / s.dim.width)))
     dim, cam, cfg = s.view(width=width, height=h, anti_alias=True, seed=1)
